@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory from the ACTUAL reference.
+
+Runs only in the development container (needs /root/reference).  The reference is imported
+read-only with its non-hot-path imports stubbed; its RNG draws are captured
+by wrapping torch.randn / Tensor.uniform_ / torch.randperm, so each fixture holds
+(inputs, captured draws, reference outputs).  Network weights are NOT stored: both sides
+rebuild them from ``oracle.mcnerf_oracle.init_params(net, seed)``.
+
+    python tests/golden/make_golden.py
+
+The .npz files it writes are committed; the reference itself never ships.
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+sys.dont_write_bytecode = True
+for m in ["cv2", "lpips", "prettytable", "torchvision", "torchvision.transforms", "apriltag",
+          "torch.utils.tensorboard"]:
+    sys.modules[m] = MagicMock()
+import matplotlib
+matplotlib.use("Agg")
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+from model.mc_nerf import NeRF_Model, MC_Model          # noqa: E402  (reference)
+from model.net_block import SinCosEmbedding, CorseFine_NeRF  # noqa: E402
+from model.net_utils import eval_sh, RAdam               # noqa: E402
+from model.loss import MC_NeRF_Loss                      # noqa: E402
+from oracle import mcnerf_oracle as O                    # noqa: E402
+
+
+# ----------------------------------------------------------------------------- RNG capture
+class Capture:
+    """Records every randn / uniform_ / randperm result while active."""
+
+    def __init__(self):
+        self.log = []
+
+    def __enter__(self):
+        self._randn, self._randperm, self._uniform = torch.randn, torch.randperm, torch.Tensor.uniform_
+        cap = self
+
+        def randn(*a, **k):
+            t = cap._randn(*a, **k)
+            cap.log.append(("randn", t.clone()))
+            return t
+
+        def randperm(*a, **k):
+            t = cap._randperm(*a, **k)
+            cap.log.append(("randperm", t.clone()))
+            return t
+
+        def uniform_(self_t, *a, **k):
+            t = cap._uniform(self_t, *a, **k)
+            cap.log.append(("uniform", t.clone()))
+            return t
+
+        torch.randn, torch.randperm, torch.Tensor.uniform_ = randn, randperm, uniform_
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randperm, torch.Tensor.uniform_ = self._randn, self._randperm, self._uniform
+
+    def of(self, kind):
+        return [t for k, t in self.log if k == kind]
+
+
+def sys_param(cfg: O.RenderCfg, mode=0, batch=128, extra=None):
+    p = dict(mode=mode, device_type="cpu", near=cfg.near, far=cfg.far, samples=cfg.samples,
+             scale=cfg.scale, MLP_deg=cfg.deg, white_back=cfg.white_back, root_weight="/tmp/w",
+             demo_render_pth="/tmp/r", batch=batch, boader_min=-3.5, boader_max=3.5, grid_nerf=384,
+             sigma_init=30.0, sigma_default=cfg.sigma_default, warmup_epoch=100,
+             sample_weight_thresh=cfg.weight_thresh, res_h=800, res_w=800, data_name="lego",
+             emb_freqs_xyz=cfg.n_freqs, barf_mask=cfg.barf_mode, barf_start=cfg.barf_start,
+             barf_end=cfg.barf_end, coarse_MLP_depth=cfg.coarse.depth, coarse_MLP_width=cfg.coarse.width,
+             coarse_MLP_skip=list(cfg.coarse.skips), fine_MLP_depth=cfg.fine.depth,
+             fine_MLP_width=cfg.fine.width, fine_MLP_skip=list(cfg.fine.skips), distributed=False)
+    if extra:
+        p.update(extra)
+    return p
+
+
+def make_rays(n, seed, radius=3.0):
+    """Unit rays from a sphere of the given radius aimed near the origin (Ball-like)."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * radius
+    tgt = (torch.rand(n, 3, generator=g) - 0.5) * 1.5
+    d = torch.nn.functional.normalize(tgt - o, dim=-1)
+    return d.contiguous(), o.contiguous()
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}.npz  ({os.path.getsize(path)/1024:.1f} KB)")
+
+
+def load_nets(model: NeRF_Model, cfg: O.RenderCfg, seed_c, seed_f, sigma_bias_shift=0.0):
+    pc, pf = O.init_params(cfg.coarse, seed_c), O.init_params(cfg.fine, seed_f)
+    if sigma_bias_shift:
+        pc["sigma.2.bias"] = pc["sigma.2.bias"] + sigma_bias_shift
+        pf["sigma.2.bias"] = pf["sigma.2.bias"] + sigma_bias_shift
+    model.nerf_coarse.load_state_dict(pc)
+    model.nerf_fine.load_state_dict(pf)
+    return pc, pf
+
+
+# ----------------------------------------------------------------------------- G1: embedding
+def g1_embed():
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(96, 3, generator=g) - 0.5) * 16.0
+    cfg = O.RenderCfg()
+    e = SinCosEmbedding(sys_param(cfg))
+    out_off = e(x, 0.5)
+    cfgb = O.RenderCfg(barf_mode=True, barf_start=0.3846, barf_end=0.6923)
+    eb = SinCosEmbedding(sys_param(cfgb))
+    outs = {f"on_{i}": eb(x, r) for i, r in enumerate([0.2, 0.45, 0.55, 0.9])}
+    npz("g1_embed", x=x, off=out_off, steps=np.array([0.2, 0.45, 0.55, 0.9], np.float64),
+        barf_start=0.3846, barf_end=0.6923, **outs)
+
+
+# ----------------------------------------------------------------------------- G2/G3: SH + MLP
+def g3_mlp():
+    g = torch.Generator().manual_seed(3)
+    M = 96
+    xyz = (torch.rand(M, 3, generator=g) - 0.5) * 8.0
+    dirs = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1)
+    sh = torch.randn(M, 3, 9, generator=g)
+    rgb_sh = eval_sh(2, sh, dirs)
+    out = dict(xyz=xyz, dirs=dirs, sh=sh, sh_rgb=rgb_sh)
+    for tag, net, seed in [("c32", O.NetCfg(4, 32, (2,)), 11), ("f64", O.NetCfg(8, 64, (4,)), 12),
+                           ("c128", O.NetCfg(4, 128, (2,)), 13), ("f256", O.NetCfg(8, 256, (4,)), 14)]:
+        cfg = O.RenderCfg(coarse=net, fine=net)
+        m = CorseFine_NeRF(sys_param(cfg), type="coarse")
+        m.load_state_dict(O.init_params(net, seed))
+        enc = SinCosEmbedding(sys_param(cfg))(xyz, 1.0)
+        out[f"out_{tag}"] = m(enc, dirs)
+        out[f"seed_{tag}"] = seed
+    npz("g3_mlp", **out)
+
+
+# ----------------------------------------------------------------------------- G4: sigma2weights
+def g4_s2w():
+    cfg = O.RenderCfg(samples=32, scale=2)
+    m = NeRF_Model(sys_param(cfg))
+    g = torch.Generator().manual_seed(4)
+    N, S = 40, 32
+    z = torch.linspace(1, 8, S).expand(N, S) + torch.rand(N, 1, generator=g) * 0.2
+    deltas = torch.cat([z[:, 1:] - z[:, :-1], 1e10 * torch.ones(N, 1)], -1)
+    sig = torch.randn(N, S, generator=g) * 4.0
+    sig[:5] = -20.0
+    sig[5:8] = 15.0
+    with Capture() as c:
+        torch.manual_seed(44)
+        w = m.sigma2weights(deltas, sig)
+    npz("g4_sigma2weights", deltas=deltas, sigmas=sig, eps=c.of("randn")[0], w=w)
+
+
+# ----------------------------------------------------------------------------- G7: train render
+def g7_train(tag, cfg: O.RenderCfg, n, seed, step_r, sigma_shift=0.0, only_coarse=False):
+    m = NeRF_Model(sys_param(cfg))
+    load_nets(m, cfg, seed + 100, seed + 200, sigma_shift)
+    m.emmbedding_xyz.barf_mode = cfg.barf_mode
+    d, o = make_rays(n, seed)
+    d.requires_grad_(True)
+    o.requires_grad_(True)
+    g = torch.Generator().manual_seed(seed + 7)
+    gt = torch.rand(n, 3, generator=g)
+    with Capture() as c:
+        torch.manual_seed(seed)
+        if only_coarse:
+            rgb_c, rgb_f, depth_c = m.render_rays_train(d, o, 0, step_r, only_coarse=True)
+        else:
+            rgb_c, rgb_f = m(d, o, 0, step_r)
+    loss = MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([rgb_c, rgb_f, gt])
+    loss.backward()
+    rn, perm = c.of("randn"), c.of("randperm")
+    arrs = dict(rays_d=d, rays_o=o, gt=gt, step_r=step_r, jitter=c.of("uniform")[0], eps_c=rn[0],
+                rgb_c=rgb_c, loss=loss, d_rays_d=d.grad, d_rays_o=o.grad, seed_c=seed + 100,
+                seed_f=seed + 200, sigma_shift=sigma_shift,
+                cfg=np.array([cfg.samples, cfg.scale, cfg.coarse.depth, cfg.coarse.width, cfg.coarse.skips[0],
+                              cfg.fine.depth, cfg.fine.width, cfg.fine.skips[0], int(cfg.barf_mode)]),
+                barf=np.array([cfg.barf_start, cfg.barf_end]))
+    if only_coarse:
+        arrs["depth_c"] = depth_c
+    else:
+        arrs.update(eps_sel=rn[1], eps_f=rn[2], rgb_f=rgb_f)
+        if perm:
+            arrs["cap_perm"] = perm[0]
+    for net_name, net in (("c", m.nerf_coarse), ("f", m.nerf_fine)):
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                continue
+            if p.numel() <= 8192:
+                arrs[f"g{net_name}.{k}"] = p.grad
+            else:   # big tensors: L2 norm + a strided sample keep the fixture small
+                arrs[f"gnorm{net_name}.{k}"] = p.grad.norm()
+                arrs[f"gsamp{net_name}.{k}"] = p.grad.reshape(-1)[::97]
+    npz(tag, **arrs)
+
+
+# ----------------------------------------------------------------------------- G8: test render
+def g8_test(tag, cfg: O.RenderCfg, n, seed, sigma_shift=0.0):
+    m = NeRF_Model(sys_param(cfg))
+    load_nets(m, cfg, seed + 100, seed + 200, sigma_shift)
+    d, o = make_rays(n, seed)
+    with Capture() as c, torch.no_grad():
+        torch.manual_seed(seed)
+        rgb, depth, opacity = m.render_rays_test(d, o, m.nerf_coarse, m.nerf_fine)
+    rn = c.of("randn")
+    npz(tag, rays_d=d, rays_o=o, eps_c=rn[0], eps_sel=rn[1], eps_f=rn[2], rgb=rgb, depth=depth,
+        opacity=opacity, seed_c=seed + 100, seed_f=seed + 200, sigma_shift=sigma_shift,
+        cfg=np.array([cfg.samples, cfg.scale, cfg.coarse.depth, cfg.coarse.width, cfg.coarse.skips[0],
+                      cfg.fine.depth, cfg.fine.width, cfg.fine.skips[0], 0]))
+
+
+# ----------------------------------------------------------------------------- G9/G10: cameras
+class _Cam(MC_Model):
+    """MC_Model with the constructor's dataset plumbing bypassed (hot-path methods only)."""
+
+    def __init__(self, C, H, W):
+        torch.nn.Module.__init__(self)
+        self.device = "cpu"
+        self.img_h, self.img_w, self.train_numb = H, W, C
+        self.register_parameters()
+
+
+def g9_cameras():
+    C, H, W = 5, 12, 20
+    cam = _Cam(C, H, W)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        cam.weights_pose.copy_(torch.randn(C, 6, generator=g) * 0.7)
+        for w in (cam.weights_fx, cam.weights_fy, cam.weights_ux, cam.weights_uy):
+            w.copy_(1.0 + 0.2 * torch.randn(C, generator=g))
+        cam.weights_fx[1] = -0.9   # exercises abs()
+    K = cam.add_weights2intr(H, W)
+    pose = cam.add_weights2pose()
+    Kinv = cam.inverse_intrinsic(K)
+    img_id = torch.tensor([3])
+    d, o = cam.get_rays(pose, img_id, Kinv)
+    gd = torch.randn(d.shape, generator=g)
+    go = torch.randn(o.shape, generator=g)
+    ((d * gd).sum() + (o * go).sum()).backward()
+    npz("g9_cameras", H=H, W=W, img_id=3, weights_pose=cam.weights_pose, weights_fx=cam.weights_fx,
+        weights_fy=cam.weights_fy, weights_ux=cam.weights_ux, weights_uy=cam.weights_uy, K=K, pose=pose,
+        Kinv=Kinv, rays_d=d, rays_o=o, gd=gd, go=go, g_weights_pose=cam.weights_pose.grad,
+        g_weights_fx=cam.weights_fx.grad, g_weights_fy=cam.weights_fy.grad,
+        g_weights_ux=cam.weights_ux.grad, g_weights_uy=cam.weights_uy.grad)
+
+
+def main():
+    torch.set_num_threads(4)
+    g1_embed()
+    g3_mlp()
+    g4_s2w()
+    small = dict(coarse=O.NetCfg(4, 32, (2,)), fine=O.NetCfg(8, 64, (4,)))
+    g7_train("g7_train_s64x2_small", O.RenderCfg(samples=64, scale=2, **small), 96, 70, 1.0)
+    g7_train("g7_train_s32x5_small_barf", O.RenderCfg(samples=32, scale=5, barf_mode=True, barf_start=0.3846,
+                                                       barf_end=0.6923, **small), 64, 71, 0.5)
+    g7_train("g7_train_s32x5_cap", O.RenderCfg(samples=32, scale=5, **small), 48, 72, 1.0, sigma_shift=-2.5)
+    g7_train("g7_train_s64x2_full", O.RenderCfg(samples=64, scale=2), 64, 73, 1.0)
+    g7_train("g7_train_s32_coarse_only", O.RenderCfg(samples=32, scale=2, **small), 64, 74, 1.0, only_coarse=True)
+    g8_test("g8_test_s64x2_small", O.RenderCfg(samples=64, scale=2, **small), 96, 80)
+    g8_test("g8_test_s64x2_full", O.RenderCfg(samples=64, scale=2), 48, 81)
+    g8_test("g8_test_s128x5_small", O.RenderCfg(samples=128, scale=5, **small), 24, 82, sigma_shift=2.0)
+    g9_cameras()
+
+
+if __name__ == "__main__":
+    main()
