@@ -1,0 +1,126 @@
+/* mcnerf.h - C ABI of the MI355X-native MC-NeRF volumetric-rendering hot path (libmcnerf.so).
+ *
+ * The reference (SkylerGao/MC_NeRF) has NO plugin / FFI layer: its hot path is eager PyTorch inside
+ * model/mc_nerf.py, model/net_block.py and model/net_utils.py.  The entry points below are therefore
+ * this build's own boundary; each one names the reference code it replaces (file:line, relative to
+ * the reference checkout).  The Python host classes in mc_nerf_amd/model mirror the reference's
+ * MC_Model / NeRF_Model API and call these functions through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates inputs, outputs,
+ *     gradients and workspaces); the library keeps no global state and frees nothing;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, there
+ *     are no host synchronisations and no internal streams;
+ *   - return value: 0 = OK, negative = error; mcnerf_last_error() returns a thread-local message;
+ *   - all floating point is fp32; sample index pairs are int32 (ray, sample); pixel ids int64;
+ *   - a net is described by (depth, width, skip): `depth` trunk layers of `width` units with the
+ *     encoded input re-concatenated ([x_enc, h]) at layer index `skip` (model/net_block.py:51-59);
+ *     widths 32, 64, 128, 256 and depth <= 8 are built;
+ *   - parameters of one net live in ONE flat fp32 buffer in the reference's state-dict order
+ *     (xyz_encoding_{1..depth}.0.{weight,bias}, sigma.0.*, sigma.2.*, sh.0.*, sh.2.*), Linear weights
+ *     [out][in] row-major; gradients use the same layout.
+ */
+#ifndef MCNERF_H
+#define MCNERF_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCNERF_ABI_VERSION 1
+
+int mcnerf_abi_version(void);
+const char* mcnerf_last_error(void);
+
+/* Sizes (in floats) of the flat parameter buffer and of the packed-weight buffer of one net, and the
+ * number of samples one workgroup tile covers (workspace capacities need no rounding; informative). */
+long long mcnerf_param_count(int depth, int width, int skip);
+long long mcnerf_packed_count(int depth, int width, int skip);
+int mcnerf_tile_rows(int width);
+/* Float offsets of the 2*depth+8 tensors (reference state-dict order) inside the flat parameter
+ * buffer; each tensor starts on a 16-byte boundary, so the buffer has a few padding floats. */
+int mcnerf_param_offsets(int depth, int width, int skip, long long* offsets);
+
+/* Re-lays the Linear weights into MFMA operand-fragment order (forward + transposed copies).
+ * Must be called after every parameter update, before mlp_fwd / mlp_bwd.  No reference
+ * counterpart (torch's addmm reads nn.Linear.weight directly, model/net_block.py:69-74). */
+int mcnerf_pack_weights(int depth, int width, int skip, const float* params, float* packed, void* stream);
+
+/* Ray generation for the selected pixels of ONE camera.
+ * Replaces MC_Model.get_rays + generate_rand_rays (model/mc_nerf.py:124-145, 327-345):
+ * pose [3,4] = world->cam [R|t], kinv [3,3], pix [n] = v*W+u  ->  rays_d [n,3] (unit), rays_o [n,3]. */
+int mcnerf_raygen_fwd(const float* pose, const float* kinv, const int64_t* pix, int n, int W,
+                      float* rays_d, float* rays_o, void* stream);
+/* Backward of the above; ACCUMULATES into d_pose [3,4] and d_kinv [3,3] (caller zeroes them). */
+int mcnerf_raygen_bwd(const float* pose, const float* kinv, const int64_t* pix, int n, int W,
+                      const float* d_rays_d, const float* d_rays_o, float* d_pose, float* d_kinv, void* stream);
+
+/* Fused sample generation + positional encoding + MLP + SH colour for one net.
+ * Replaces the gather/encode/MLP/scatter part of NeRF_Model.inference (model/mc_nerf.py:688-701),
+ * SinCosEmbedding.forward (model/net_block.py:20-35), CorseFine_NeRF.forward (model/net_block.py:67-78)
+ * and eval_sh (model/net_utils.py:103-191).
+ *   rays_o, rays_d [n_rays,3]; zgrid [S] = linspace(near,far,S); jitter [n_rays] or NULL;
+ *   barf_w [10] per-frequency mask (ones when BARF is off);
+ *   idx  NULL  -> dense: every (ray, sample) of the [n_rays,S] grid is evaluated (coarse pass);
+ *        !NULL -> [max_rows] int32 (ray, sample) pairs, *count of them valid (fine pass); workgroups
+ *                 beyond *count exit, so no host sync is needed to size the launch;
+ *   out  [n_rays,S,4] = (sigma_raw, r, g, b) written at (ray, sample); entries not listed in idx are
+ *        left untouched (mcnerf_select_fine pre-fills the reference's defaults);
+ *   act_save / enc_save / sh_save: NULL for the no-grad path; otherwise workspaces of
+ *        (depth+2)*capacity*width, capacity*64 and capacity*32 floats that receive what
+ *        mcnerf_mlp_bwd / mcnerf_mlp_dw need (capacity >= number of evaluated samples). */
+int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const float* packed,
+                   const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
+                   const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
+                   int n_rays, int S, float* out,
+                   float* act_save, long long capacity, float* enc_save, float* sh_save, void* stream);
+
+/* Backward of mcnerf_mlp_fwd wrt the activations (the dX chain): consumes d_out [n_rays,S,4],
+ * writes the pre-activation gradients of every layer to dy_save ((depth+2)*capacity*width floats) and
+ * dsh_save (capacity*32), ACCUMULATES d_rays_o / d_rays_d [n_rays,3] (through the sample positions,
+ * the encoding and the SH view direction; either may be NULL) and ACCUMULATES the gradients of the
+ * 1-wide sigma.2 layer into `grads` (flat parameter layout; the other weight gradients come from
+ * mcnerf_mlp_dw).
+ * Replaces autograd through model/net_block.py:22-33, 67-78 and model/mc_nerf.py:602, 635, 690-691. */
+int mcnerf_mlp_bwd(int depth, int width, int skip, const float* params, const float* packed,
+                   const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
+                   const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
+                   int n_rays, int S, const float* out, const float* d_out,
+                   const float* act_save, long long capacity, const float* enc_save, const float* sh_save,
+                   float* grads, float* dy_save, float* dsh_save, float* d_rays_o, float* d_rays_d, void* stream);
+
+/* Weight / bias gradients of one net: dW_l = dY_l^T X_l, db_l = sum_rows dY_l, ACCUMULATED into
+ * `grads` (flat, same layout as the parameters; caller zeroes it once per step).
+ * `count` NULL -> `rows` rows are valid; otherwise *count (<= rows). */
+int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows,
+                  const float* act_save, const float* enc_save, const float* dy_save, const float* dsh_save,
+                  long long capacity, float* grads, void* stream);
+
+/* Alpha compositing of [N,S] samples per ray.
+ * Replaces NeRF_Model.inference's compositing (model/mc_nerf.py:705-727) and sigma2weights
+ * (model/mc_nerf.py:729-736); the N(0,1) draws of sigma2weights are explicit inputs.
+ *   eps [N,S]: draw of the rgb composite; eps_sel [N,S] or NULL: draw of the selection weights
+ *   (model/mc_nerf.py:619 / 662), which are written to w_sel [N,S] and max-reduced into *wmax_bits
+ *   (float bits; caller zeroes it);  depth/opacity [N] may be NULL (training). */
+int mcnerf_composite_fwd(const float* sig_rgb, const float* rays_d, const float* zgrid, const float* jitter,
+                         const float* eps, const float* eps_sel, int N, int S, int white_back,
+                         float* rgb, float* depth, float* opacity, float* w_sel, uint32_t* wmax_bits, void* stream);
+/* Backward of the rgb composite: d_rgb [N,3] -> d_sig_rgb [N,S,4]. */
+int mcnerf_composite_bwd(const float* sig_rgb, const float* zgrid, const float* jitter, const float* eps,
+                         const float* d_rgb, int N, int S, int white_back, float* d_sig_rgb, void* stream);
+
+/* Weight-threshold fine-sample selection (model/mc_nerf.py:623-629): every coarse sample with
+ * w_sel >= min(thresh, max w_sel) contributes `scale` fine samples (ray, j*scale + r), emitted in
+ * torch.nonzero order into idx [N*Sc*scale] (int32 pairs) with the total in *count.  out_f
+ * [N,Sc*scale,4] (or NULL) is pre-filled with (sigma_default, 1, 1, 1) (model/mc_nerf.py:692-694).
+ * ray_counts / ray_offsets: int32 [N] workspaces. */
+int mcnerf_select_fine(const float* w_sel, const uint32_t* wmax_bits, float thresh, int N, int Sc, int scale,
+                       float sigma_default, int32_t* ray_counts, int32_t* ray_offsets,
+                       int32_t* idx, int32_t* count, float* out_f, void* stream);
+/* The random cap of model/mc_nerf.py:630-632: idx_out[i] = idx_in[perm[i]], i < keep; *count = keep. */
+int mcnerf_cap_gather(const int32_t* idx_in, const int64_t* perm, int keep, int32_t* idx_out, int32_t* count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCNERF_H */

@@ -1,0 +1,61 @@
+"""Builds mc_nerf_amd/libmcnerf.so (hipcc, gfx950 only) in-tree.
+
+    python -m mc_nerf_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the .so travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libmcnerf.so")
+SOURCES = ["api.hip", "pack.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_dw.hip", "composite.hip", "select_raygen.hip"]
+HEADERS = ["mcnerf_common.h", "mcnerf_kernels.h", os.path.join("..", "..", "include", "mcnerf.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return src, r.returncode, r.stdout + r.stderr
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        for src, rc, log in ex.map(cc, jobs):
+            if verbose and log.strip():
+                print(log)
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed on {src}\n{log}")
+            if verbose:
+                print(f"[mc_nerf_amd.build] compiled {os.path.basename(src)}")
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if jobs or not os.path.exists(OUT):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed\n" + r.stdout + r.stderr)
+        if verbose:
+            print(f"[mc_nerf_amd.build] linked {OUT}")
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,153 @@
+// C ABI of libmcnerf.so (see include/mcnerf.h).  Thin argument checking + launcher calls; every
+// kernel is enqueued on the caller's stream, nothing here synchronises or allocates.
+#include "../../include/mcnerf.h"
+#include "mcnerf_kernels.h"
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char* where, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, what);
+    return -1;
+}
+static int check(const char* where, hipError_t e) {
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", where, (int)e, hipGetErrorString(e));
+    return -2;
+}
+static bool net_ok(int depth, int width, int skip) {
+    (void)skip;
+    return depth >= 1 && depth <= MCN_MAXD && (width == 32 || width == 64 || width == 128 || width == 256);
+}
+#define REQ(cond, name) do { if (!(cond)) return fail(name, "invalid argument: " #cond); } while (0)
+
+extern "C" {
+
+int mcnerf_abi_version(void) { return MCNERF_ABI_VERSION; }
+const char* mcnerf_last_error(void) { return g_err; }
+
+long long mcnerf_param_count(int depth, int width, int skip) {
+    if (!net_ok(depth, width, skip)) return -1;
+    return mcn_make_layout(depth, width, skip).n_params;
+}
+long long mcnerf_packed_count(int depth, int width, int skip) {
+    if (!net_ok(depth, width, skip)) return -1;
+    return mcn_make_layout(depth, width, skip).n_packed;
+}
+int mcnerf_tile_rows(int width) { return mcn_mlp_tile_rows(width); }
+
+int mcnerf_param_offsets(int depth, int width, int skip, long long* offsets) {
+    REQ(net_ok(depth, width, skip) && offsets, "mcnerf_param_offsets");
+    const McnLayout L = mcn_make_layout(depth, width, skip);
+    int k = 0;
+    for (int i = 0; i < depth; ++i) { offsets[k++] = L.pW[i]; offsets[k++] = L.pB[i]; }
+    offsets[k++] = L.pWs1; offsets[k++] = L.pBs1; offsets[k++] = L.pWs2; offsets[k++] = L.pBs2;
+    offsets[k++] = L.pWc1; offsets[k++] = L.pBc1; offsets[k++] = L.pWc2; offsets[k++] = L.pBc2;
+    return 0;
+}
+
+int mcnerf_pack_weights(int depth, int width, int skip, const float* params, float* packed, void* stream) {
+    REQ(net_ok(depth, width, skip) && params && packed, "mcnerf_pack_weights");
+    return check("mcnerf_pack_weights", mcn_launch_pack(mcn_make_layout(depth, width, skip), params, packed, (hipStream_t)stream));
+}
+
+int mcnerf_raygen_fwd(const float* pose, const float* kinv, const int64_t* pix, int n, int W,
+                      float* rays_d, float* rays_o, void* stream) {
+    REQ(pose && kinv && pix && rays_d && rays_o && n >= 0 && W > 0, "mcnerf_raygen_fwd");
+    McnRaygenArgs a = {pose, kinv, (const long long*)pix, n, W, rays_d, rays_o};
+    return check("mcnerf_raygen_fwd", mcn_launch_raygen_fwd(a, (hipStream_t)stream));
+}
+int mcnerf_raygen_bwd(const float* pose, const float* kinv, const int64_t* pix, int n, int W,
+                      const float* d_rays_d, const float* d_rays_o, float* d_pose, float* d_kinv, void* stream) {
+    REQ(pose && kinv && pix && d_rays_d && d_rays_o && d_pose && d_kinv && n >= 0 && W > 0, "mcnerf_raygen_bwd");
+    McnRaygenBwdArgs a = {pose, kinv, (const long long*)pix, n, W, d_rays_d, d_rays_o, d_pose, d_kinv};
+    return check("mcnerf_raygen_bwd", mcn_launch_raygen_bwd(a, (hipStream_t)stream));
+}
+
+int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const float* packed,
+                   const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
+                   const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
+                   int n_rays, int S, float* out,
+                   float* act_save, long long capacity, float* enc_save, float* sh_save, void* stream) {
+    REQ(net_ok(depth, width, skip), "mcnerf_mlp_fwd");
+    REQ(params && packed && rays_o && rays_d && zgrid && barf_w && out && n_rays >= 0 && S > 0, "mcnerf_mlp_fwd");
+    REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_fwd");
+    REQ(!idx || max_rows >= 0, "mcnerf_mlp_fwd");
+    REQ((long long)n_rays * S < (1ll << 31), "mcnerf_mlp_fwd");
+    if (act_save) {
+        REQ(enc_save && sh_save, "mcnerf_mlp_fwd");
+        REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_fwd");
+    }
+    McnMlpFwdArgs a;
+    a.lay = mcn_make_layout(depth, width, skip);
+    a.params = params; a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter;
+    a.barf_w = barf_w; a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
+    a.out = out; a.act_save = act_save; a.act_stride = (size_t)capacity * width; a.enc_save = enc_save; a.sh_save = sh_save;
+    return check("mcnerf_mlp_fwd", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
+}
+
+int mcnerf_mlp_bwd(int depth, int width, int skip, const float* params, const float* packed,
+                   const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
+                   const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
+                   int n_rays, int S, const float* out, const float* d_out,
+                   const float* act_save, long long capacity, const float* enc_save, const float* sh_save,
+                   float* grads, float* dy_save, float* dsh_save, float* d_rays_o, float* d_rays_d, void* stream) {
+    REQ(net_ok(depth, width, skip), "mcnerf_mlp_bwd");
+    REQ(params && packed && rays_o && rays_d && zgrid && barf_w && out && d_out && n_rays >= 0 && S > 0, "mcnerf_mlp_bwd");
+    REQ(act_save && enc_save && sh_save && dy_save && dsh_save, "mcnerf_mlp_bwd");
+    REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_bwd");
+    REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_bwd");
+    McnMlpBwdArgs a;
+    a.lay = mcn_make_layout(depth, width, skip);
+    a.params = params; a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter;
+    a.barf_w = barf_w; a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
+    a.out = out; a.d_out = d_out; a.act_save = act_save; a.act_stride = (size_t)capacity * width;
+    a.enc_save = enc_save; a.sh_save = sh_save; a.grads = grads; a.dy_save = dy_save; a.dsh_save = dsh_save;
+    a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d;
+    return check("mcnerf_mlp_bwd", mcn_launch_mlp_bwd(a, (hipStream_t)stream));
+}
+
+int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows,
+                  const float* act_save, const float* enc_save, const float* dy_save, const float* dsh_save,
+                  long long capacity, float* grads, void* stream) {
+    REQ(net_ok(depth, width, skip), "mcnerf_mlp_dw");
+    REQ(act_save && enc_save && dy_save && dsh_save && grads && rows >= 0 && capacity >= rows, "mcnerf_mlp_dw");
+    McnDwArgs a;
+    a.lay = mcn_make_layout(depth, width, skip);
+    a.count = count; a.rows = rows; a.act_save = act_save; a.enc_save = enc_save; a.dy_save = dy_save;
+    a.dsh_save = dsh_save; a.act_stride = (size_t)capacity * width; a.grads = grads;
+    return check("mcnerf_mlp_dw", mcn_launch_dw(a, (hipStream_t)stream));
+}
+
+int mcnerf_composite_fwd(const float* sig_rgb, const float* rays_d, const float* zgrid, const float* jitter,
+                         const float* eps, const float* eps_sel, int N, int S, int white_back,
+                         float* rgb, float* depth, float* opacity, float* w_sel, uint32_t* wmax_bits, void* stream) {
+    REQ(sig_rgb && rays_d && zgrid && eps && rgb && N >= 0 && S > 0, "mcnerf_composite_fwd");
+    REQ((depth == nullptr) == (opacity == nullptr), "mcnerf_composite_fwd");
+    REQ(!eps_sel || w_sel, "mcnerf_composite_fwd");
+    McnCompositeArgs a = {sig_rgb, rays_d, zgrid, jitter, eps, eps_sel, N, S, white_back, rgb, depth, opacity, w_sel, wmax_bits};
+    return check("mcnerf_composite_fwd", mcn_launch_composite_fwd(a, (hipStream_t)stream));
+}
+int mcnerf_composite_bwd(const float* sig_rgb, const float* zgrid, const float* jitter, const float* eps,
+                         const float* d_rgb, int N, int S, int white_back, float* d_sig_rgb, void* stream) {
+    REQ(sig_rgb && zgrid && eps && d_rgb && d_sig_rgb && N >= 0 && S > 0, "mcnerf_composite_bwd");
+    REQ((size_t)4 * 5 * S * sizeof(float) <= 160 * 1024, "mcnerf_composite_bwd");
+    McnCompositeBwdArgs a = {sig_rgb, zgrid, jitter, eps, d_rgb, N, S, white_back, d_sig_rgb};
+    return check("mcnerf_composite_bwd", mcn_launch_composite_bwd(a, (hipStream_t)stream));
+}
+
+int mcnerf_select_fine(const float* w_sel, const uint32_t* wmax_bits, float thresh, int N, int Sc, int scale,
+                       float sigma_default, int32_t* ray_counts, int32_t* ray_offsets,
+                       int32_t* idx, int32_t* count, float* out_f, void* stream) {
+    REQ(w_sel && wmax_bits && ray_counts && ray_offsets && idx && count && N >= 0 && Sc > 0 && scale > 0, "mcnerf_select_fine");
+    REQ((long long)N * Sc * scale < (1ll << 31), "mcnerf_select_fine");
+    McnSelectArgs a = {w_sel, wmax_bits, thresh, N, Sc, scale, sigma_default, ray_counts, ray_offsets, (int2*)idx, count, out_f};
+    return check("mcnerf_select_fine", mcn_launch_select(a, (hipStream_t)stream));
+}
+int mcnerf_cap_gather(const int32_t* idx_in, const int64_t* perm, int keep, int32_t* idx_out, int32_t* count, void* stream) {
+    REQ(idx_in && perm && idx_out && count && keep >= 0, "mcnerf_cap_gather");
+    return check("mcnerf_cap_gather", mcn_launch_cap_gather((const int2*)idx_in, (const long long*)perm, keep, (int2*)idx_out, count, (hipStream_t)stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+// Shared device/host definitions for the MC-NeRF gfx950 kernels.
+//
+// Data layout conventions:
+//  * Network parameters live in ONE flat fp32 buffer per net in the reference's state-dict order
+//    (model/net_block.py:51-65): xyz_encoding_{1..D}.0.{weight,bias}, sigma.0.*, sigma.2.*,
+//    sh.0.*, sh.2.*; Linear weights are [out][in] row-major.
+//  * Before use the weights are re-laid ("packed") into MFMA operand-fragment order so that one
+//    wave's A-operand load for (n-tile, k-step) is a single contiguous 1 KiB global_load_dwordx4.
+//  * Activations of a tile of MT samples live in LDS as X[MT][XW] fp32 with a 16-byte-chunk XOR
+//    swizzle (chunk ^= row & 15) so that ds_read_b128 of 32 different rows at one k is conflict-free.
+//  * All GEMMs use v_mfma_f32_32x32x2_f32 (exact fp32, == fmaf chain) in the "sample on the lane"
+//    orientation: D[n][m] = sum_k W[n][k] * X[m][k]; lane&31 = sample m, accumulator regs = n.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MCN_MAXD 8          // max trunk depth
+#define MCN_ENC 63          // 3 + 3*2*10 encoded channels (model/net_block.py:17)
+#define MCN_ENCP 64         // padded
+#define MCN_NFREQ 10
+#define MCN_NSH 27          // 3 * (deg+1)^2, deg = 2
+#define MCN_NSHP 32
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Offsets (in floats) of every tensor of one CorseFine_NeRF inside (a) the flat parameter buffer and
+// (b) the packed buffer.  Built on the host by mcn_make_layout(), passed to kernels by value.
+struct McnLayout {
+    int depth, width, skip;
+    // flat parameter buffer (reference order)
+    int pW[MCN_MAXD], pB[MCN_MAXD];
+    int pWs1, pBs1, pWs2, pBs2, pWc1, pBc1, pWc2, pBc2;
+    int n_params;
+    // packed, forward orientation: P[ntile][kstep][lane][4] = W[32*ntile + (lane&31)][8*kstep + 4*(lane>>5) + i]
+    int fEnc0;               // layer 0, K = 64 (63 padded)
+    int fH[MCN_MAXD];        // layers >= 1: the hidden-input segment (K = width)
+    int fEncS;               // skip layer: the encoded-input segment (K = 64)
+    int fS1, fC1;            // sigma.0, sh.0
+    int fC2;                 // sh.2 (N = 32, 27 padded)
+    // packed, transposed orientation (for dX = W^T dY): PT[ktile][nstep][lane][4] = W[8*nstep + 4*(lane>>5) + i][32*ktile + (lane&31)]
+    int bEnc0, bH[MCN_MAXD], bEncS, bS1, bC1, bC2;
+    int n_packed;
+};
+
+static inline int mcn_in_features(int depth, int width, int skip, int i) {
+    if (i == 0) return MCN_ENC;
+    return (i == skip) ? width + MCN_ENC : width;
+}
+
+static inline McnLayout mcn_make_layout(int depth, int width, int skip) {
+    McnLayout L;
+    L.depth = depth; L.width = width; L.skip = skip;
+    int o = 0;
+    // every tensor starts on a 16-byte boundary so that float4 loads of biases / weight rows are aligned
+    auto al = [&o]() { o = (o + 3) & ~3; return o; };
+    for (int i = 0; i < MCN_MAXD; ++i) { L.pW[i] = L.pB[i] = 0; L.fH[i] = L.bH[i] = 0; }
+    for (int i = 0; i < depth; ++i) {
+        L.pW[i] = al(); o += width * mcn_in_features(depth, width, skip, i);
+        L.pB[i] = al(); o += width;
+    }
+    L.pWs1 = al(); o += width * width; L.pBs1 = al(); o += width;
+    L.pWs2 = al(); o += width;         L.pBs2 = al(); o += 1;
+    L.pWc1 = al(); o += width * width; L.pBc1 = al(); o += width;
+    L.pWc2 = al(); o += MCN_NSH * width; L.pBc2 = al(); o += MCN_NSH;
+    al();
+    L.n_params = o;
+    int q = 0;
+    L.fEnc0 = q; q += width * MCN_ENCP;
+    for (int i = 1; i < depth; ++i) { L.fH[i] = q; q += width * width; }
+    L.fEncS = q; q += width * MCN_ENCP;
+    L.fS1 = q; q += width * width;
+    L.fC1 = q; q += width * width;
+    L.fC2 = q; q += MCN_NSHP * width;
+    L.bEnc0 = q; q += width * MCN_ENCP;
+    for (int i = 1; i < depth; ++i) { L.bH[i] = q; q += width * width; }
+    L.bEncS = q; q += width * MCN_ENCP;
+    L.bS1 = q; q += width * width;
+    L.bC1 = q; q += width * width;
+    L.bC2 = q; q += MCN_NSHP * width;
+    L.n_packed = q;
+    return L;
+}
+
+// Tile geometry per width: 8 waves = WN (along outputs) x WM (along samples);
+// each wave owns NI x MI MFMA tiles of 32x32.
+template <int WIDTH> struct McnGeom;
+template <> struct McnGeom<256> { static constexpr int WN = 4, NI = 2, WM = 2, MI = 2; };
+template <> struct McnGeom<128> { static constexpr int WN = 4, NI = 1, WM = 2, MI = 2; };
+template <> struct McnGeom<64>  { static constexpr int WN = 2, NI = 1, WM = 4, MI = 1; };
+template <> struct McnGeom<32>  { static constexpr int WN = 1, NI = 1, WM = 8, MI = 1; };
+
+#ifdef __HIPCC__
+// Swizzled float offset of element (row m, column k) in an LDS tile with XW floats per row.
+__device__ __forceinline__ int mcn_swz(int m, int k, int xw) {
+    return m * xw + ((((k >> 2) ^ (m & 15)) << 2) | (k & 3));
+}
+// Same, for a 16-byte chunk index.
+__device__ __forceinline__ int mcn_swz_chunk(int m, int chunk, int xw) {
+    return m * xw + ((chunk ^ (m & 15)) << 2);
+}
+
+// acc[ni][mi] += W-fragment x X-fragment over KS k-steps of 8.
+//   P  : packed weights for this wave's first n-tile, float4 units, laid out [ni][KS][64 lanes]
+//   X  : LDS tile; rows mrow0 + mi*32 + (lane&31); the segment starts at 16-B chunk `kchunk0`
+// The weight fragments are read straight from global memory (L2-resident) one k-step ahead.
+template <int NI, int MI>
+__device__ __forceinline__ void mcn_gemm_seg(f32x16 (&acc)[NI][MI], const float* X, int xw, int mrow0,
+                                             int kchunk0, int KS, const f32x4* __restrict__ P, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    f32x4 a_n[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) a_n[ni] = P[(ni * KS) * 64 + lane];
+    for (int ks = 0; ks < KS; ++ks) {
+        f32x4 a_c[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) a_c[ni] = a_n[ni];
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) a_n[ni] = P[(ni * KS + ks + 1) * 64 + lane];
+        }
+        f32x4 b[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = mrow0 + mi * 32 + r;
+            b[mi] = *reinterpret_cast<const f32x4*>(&X[mcn_swz_chunk(m, kchunk0 + 2 * ks + h, xw)]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[ni][i], b[mi][i], acc[ni][mi], 0, 0, 0);
+    }
+}
+
+template <int NI, int MI>
+__device__ __forceinline__ void mcn_zero(f32x16 (&acc)[NI][MI]) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ni][mi][e] = 0.f;
+}
+
+// The nine signed deg-2 SH basis factors of eval_sh (model/net_utils.py:154-169).
+__device__ __forceinline__ void mcn_sh_basis(float x, float y, float z, float (&b)[9]) {
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C20 = 1.0925484305920792f, C22 = 0.31539156525252005f, C24 = 0.5462742152960396f;
+    b[0] = C0;
+    b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
+    b[4] = C20 * (x * y); b[5] = -C20 * (y * z);
+    b[6] = C22 * (2.0f * z * z - x * x - y * y);
+    b[7] = -C20 * (x * z); b[8] = C24 * (x * x - y * y);
+}
+#endif  // __HIPCC__

@@ -1,0 +1,132 @@
+// Internal launcher interface between the C-ABI (api.hip) and the kernel translation units.
+#pragma once
+#include "mcnerf_common.h"
+
+struct McnMlpFwdArgs {
+    McnLayout lay;
+    const float* params;      // flat parameter buffer (biases, sigma.2 / sh.2 biases are read from here)
+    const float* packed;      // packed weights (mcn_launch_pack)
+    const float* rays_o;      // [n_rays,3]
+    const float* rays_d;      // [n_rays,3]
+    const float* zgrid;       // [S]  linspace(near, far, S)
+    const float* jitter;      // [n_rays] or null
+    const float* barf_w;      // [10] per-frequency mask
+    const int2* idx;          // [rows] (ray, sample) pairs, or null = dense ray-major
+    const int* count;         // device row count (with idx), or null
+    int max_rows;             // capacity of idx / upper bound on *count
+    int n_rays, S;
+    float* out;               // [n_rays,S,4] (sigma_raw, r, g, b), written at ray*S + sample
+    float* act_save;          // [(depth+2)][act_stride] post-ReLU activations, or null (no-grad path)
+    size_t act_stride;        // floats between layers = capacity * width
+    float* enc_save;          // [capacity][64]
+    float* sh_save;           // [capacity][32]
+};
+hipError_t mcn_launch_mlp_fwd(const McnMlpFwdArgs& a, hipStream_t st);
+int mcn_mlp_tile_rows(int width);
+
+struct McnMlpBwdArgs {
+    McnLayout lay;
+    const float* params;
+    const float* packed;
+    const float* rays_o;
+    const float* rays_d;
+    const float* zgrid;
+    const float* jitter;
+    const float* barf_w;
+    const int2* idx;
+    const int* count;
+    int max_rows;
+    int n_rays, S;
+    const float* out;         // forward output [n_rays,S,4]
+    const float* d_out;       // upstream gradient [n_rays,S,4]
+    const float* act_save;    // forward activations
+    size_t act_stride;
+    const float* enc_save;    // [capacity][64] encoded inputs (already BARF-weighted)
+    const float* sh_save;
+    float* grads;             // flat gradient buffer: only d sigma.2.{weight,bias} are added here (may be null)
+    float* dy_save;           // [(depth+2)][act_stride] pre-activation gradients (dW operands)
+    float* dsh_save;          // [capacity][32] gradient of the sh.2 outputs
+    float* d_rays_o;          // [n_rays,3] accumulated with atomics (may be null)
+    float* d_rays_d;          // [n_rays,3]
+};
+hipError_t mcn_launch_mlp_bwd(const McnMlpBwdArgs& a, hipStream_t st);
+
+struct McnDwArgs {
+    McnLayout lay;
+    const int* count;         // device row count or null
+    int rows;                 // rows when count == null, capacity otherwise
+    const float* act_save;
+    const float* enc_save;
+    const float* dy_save;
+    const float* dsh_save;
+    size_t act_stride;
+    float* grads;             // flat gradient buffer (same layout as params), accumulated with atomics
+};
+hipError_t mcn_launch_dw(const McnDwArgs& a, hipStream_t st);
+
+hipError_t mcn_launch_pack(const McnLayout& lay, const float* params, float* packed, hipStream_t st);
+
+struct McnCompositeArgs {
+    const float* sig_rgb;     // [N,S,4]
+    const float* rays_d;      // [N,3]
+    const float* zgrid;       // [S]
+    const float* jitter;      // [N] or null
+    const float* eps;         // [N,S] noise of the rgb composite
+    const float* eps_sel;     // [N,S] noise of the selection weights, or null
+    int N, S;
+    int white_back;
+    float* rgb;               // [N,3]
+    float* depth;             // [N] or null
+    float* opacity;           // [N] or null
+    float* w_sel;             // [N,S] or null
+    unsigned int* wmax_bits;  // running max of w_sel as float bits (weights are >= 0), or null
+};
+hipError_t mcn_launch_composite_fwd(const McnCompositeArgs& a, hipStream_t st);
+
+struct McnCompositeBwdArgs {
+    const float* sig_rgb;     // [N,S,4]
+    const float* zgrid;
+    const float* jitter;
+    const float* eps;
+    const float* d_rgb;       // [N,3]
+    int N, S;
+    int white_back;
+    float* d_sig_rgb;         // [N,S,4]
+};
+hipError_t mcn_launch_composite_bwd(const McnCompositeBwdArgs& a, hipStream_t st);
+
+struct McnSelectArgs {
+    const float* w_sel;       // [N,Sc]
+    const unsigned int* wmax_bits;
+    float thresh;
+    int N, Sc, scale;
+    float sigma_default;
+    int* ray_counts;          // [N] workspace
+    int* ray_offsets;         // [N] workspace
+    int2* idx;                // [N*Sc*scale] out
+    int* count;               // out (device)
+    float* out_f;             // [N,Sc*scale,4] prefilled with (sigma_default,1,1,1), or null
+};
+hipError_t mcn_launch_select(const McnSelectArgs& a, hipStream_t st);
+hipError_t mcn_launch_cap_gather(const int2* idx_in, const long long* perm, int keep, int2* idx_out, int* count, hipStream_t st);
+
+struct McnRaygenArgs {
+    const float* pose;        // [3,4] world->cam
+    const float* kinv;        // [3,3]
+    const long long* pix;     // [n] pixel ids (v*W+u)
+    int n, W;
+    float* rays_d;            // [n,3]
+    float* rays_o;            // [n,3]
+};
+hipError_t mcn_launch_raygen_fwd(const McnRaygenArgs& a, hipStream_t st);
+struct McnRaygenBwdArgs {
+    const float* pose;
+    const float* kinv;
+    const long long* pix;
+    int n, W;
+    const float* d_rays_d;    // [n,3]
+    const float* d_rays_o;    // [n,3]
+    float* d_pose;            // [12] accumulated (atomics)
+    float* d_kinv;            // [9]
+};
+hipError_t mcn_launch_raygen_bwd(const McnRaygenBwdArgs& a, hipStream_t st);

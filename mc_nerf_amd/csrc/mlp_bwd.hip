@@ -1,0 +1,273 @@
+// Fused NeRF MLP backward (activation-gradient chain) for gfx950.
+//
+// Replaces autograd through CorseFine_NeRF.forward / eval_sh / sigmoid (model/net_block.py:67-78,
+// model/net_utils.py:103-191), SinCosEmbedding.forward (model/net_block.py:20-35) and the sample
+// position arithmetic (model/mc_nerf.py:602, 635, 690-691).
+//
+// One workgroup = one tile of MT samples, same geometry as the forward kernel.  The LDS tile holds
+// dY (gradient wrt a layer's pre-activation); dX = W^T dY is an MFMA GEMM against the TRANSPOSED
+// packed weights; the ReLU mask of the producing layer comes from the saved forward activations.
+// Every dY is also written to dy_save: it is the A operand of the weight-gradient kernel (mlp_dw.hip).
+#include "mcnerf_common.h"
+#include "mcnerf_kernels.h"
+
+template <int WIDTH>
+struct BwdSmem {
+    using G = McnGeom<WIDTH>;
+    static constexpr int MT = G::WM * G::MI * 32;
+    static constexpr int XW = WIDTH > 64 ? WIDTH : 64;
+    static constexpr int oX = 0;
+    static constexpr int oDsig = oX + MT * XW;        // [MT] d sigma_raw
+    static constexpr int oDdir = oDsig + MT;          // [MT][4] d view-direction from the SH colour
+    static constexpr int oRed = oDdir + MT * 4;       // [512] reduction scratch
+    static constexpr int oAddr = oRed + 512;          // [MT] int ray id (or -1)
+    static constexpr int oZ = oAddr + MT;             // [MT] z value
+    static constexpr int total = oZ + MT;
+    static constexpr size_t bytes = (size_t)total * 4;
+};
+
+// acc (gradient wrt a post-ReLU activation) -> masked by (h > 0) -> LDS tile + dy_save.
+template <int WIDTH, int NI, int MI>
+__device__ __forceinline__ void mask_store(f32x16 (&acc)[NI][MI], const float* __restrict__ hsave, float* __restrict__ dysave,
+                                           float* X, int xw, int mrow0, int ncol0, long long row0, long long total, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k4 = ncol0 + ni * 32 + 8 * q + 4 * h;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = mrow0 + mi * 32 + r;
+                const bool ok = row0 + m < total;
+                f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+                if (ok) hv = *reinterpret_cast<const f32x4*>(hsave + (size_t)(row0 + m) * WIDTH + k4);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = hv[e] > 0.f ? acc[ni][mi][4 * q + e] : 0.f;
+                *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, k4 >> 2, xw)]) = v;
+                if (ok) *reinterpret_cast<f32x4*>(dysave + (size_t)(row0 + m) * WIDTH + k4) = v;
+            }
+        }
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(512) void mlp_bwd_kernel(McnMlpBwdArgs a) {
+    using G = McnGeom<WIDTH>;
+    using SM = BwdSmem<WIDTH>;
+    constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN;
+    constexpr int NSH = WIDTH / 8;            // reduction steps over a hidden-wide dY
+    constexpr int W4 = WIDTH / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem + SM::oX;
+    float* sdsig = smem + SM::oDsig;
+    float* sddir = smem + SM::oDdir;
+    float* sred = smem + SM::oRed;
+    int* sray = reinterpret_cast<int*>(smem + SM::oAddr);
+    float* sz = smem + SM::oZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
+    const int mrow0 = wm * MI * 32, ncol0 = wn * NI * 32;
+    const long long total = a.count ? (long long)min(*a.count, a.max_rows) : (long long)a.n_rays * a.S;
+    const long long row0 = (long long)blockIdx.x * MT;
+    if (row0 >= total) return;
+    const McnLayout& L = a.lay;
+    const int D = L.depth;
+    const float* __restrict__ prm = a.params;
+    const f32x4* __restrict__ pk = reinterpret_cast<const f32x4*>(a.packed);
+    const size_t AS = a.act_stride;
+
+    // ---- per-sample prologue: sigmoid and SH backward -> dsh (the dY of sh.2), d sigma, d dir
+    float bs2_part = 0.f;
+    for (int m = tid; m < MT; m += 512) {
+        const long long g = row0 + m;
+        __attribute__((aligned(16))) float dsh[MCN_NSHP];
+#pragma unroll
+        for (int i = 0; i < MCN_NSHP; ++i) dsh[i] = 0.f;
+        float dsg = 0.f, ddx = 0.f, ddy = 0.f, ddz = 0.f, zv = 0.f;
+        int ray = -1;
+        if (g < total) {
+            int j;
+            if (a.idx) { const int2 rj = a.idx[g]; ray = rj.x; j = rj.y; }
+            else { ray = (int)(g / a.S); j = (int)(g - (long long)ray * a.S); }
+            zv = a.zgrid[j];
+            if (a.jitter) zv = __fadd_rn(zv, a.jitter[ray]);
+            const size_t addr = (size_t)ray * a.S + j;
+            const f32x4 o = *reinterpret_cast<const f32x4*>(a.out + addr * 4);
+            const f32x4 go = *reinterpret_cast<const f32x4*>(a.d_out + addr * 4);
+            dsg = go[0];
+            const float x = a.rays_d[ray * 3], y = a.rays_d[ray * 3 + 1], z = a.rays_d[ray * 3 + 2];
+            float b[9];
+            mcn_sh_basis(x, y, z, b);
+            const float* sh = a.sh_save + (size_t)g * MCN_NSHP;
+            const float C1 = 0.4886025119029199f, C20 = 1.0925484305920792f, C22 = 0.31539156525252005f,
+                        C24 = 0.5462742152960396f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float dpre = go[1 + c] * o[1 + c] * (1.f - o[1 + c]);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) dsh[9 * c + i] = dpre * b[i];
+                const float* s = sh + 9 * c;
+                // d(pre)/d(dir): derivatives of the nine basis polynomials
+                ddx += dpre * (-C1 * s[3] + C20 * y * s[4] - 2.f * C22 * x * s[6] - C20 * z * s[7] + 2.f * C24 * x * s[8]);
+                ddy += dpre * (-C1 * s[1] + C20 * x * s[4] - C20 * z * s[5] - 2.f * C22 * y * s[6] - 2.f * C24 * y * s[8]);
+                ddz += dpre * (C1 * s[2] - C20 * y * s[5] + 4.f * C22 * z * s[6] - C20 * x * s[7]);
+            }
+            float* dst = a.dsh_save + (size_t)g * MCN_NSHP;
+#pragma unroll
+            for (int i = 0; i < MCN_NSHP; i += 4) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<f32x4*>(&dsh[i]);
+        }
+#pragma unroll
+        for (int c4 = 0; c4 < MCN_NSHP / 4; ++c4)
+            *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, c4, XW)]) = *reinterpret_cast<f32x4*>(&dsh[4 * c4]);
+        sdsig[m] = dsg; sray[m] = ray; sz[m] = zv;
+        sddir[m * 4] = ddx; sddir[m * 4 + 1] = ddy; sddir[m * 4 + 2] = ddz; sddir[m * 4 + 3] = 0.f;
+        bs2_part += dsg;
+    }
+    __syncthreads();
+
+    f32x16 acc[NI][MI];
+    // ---- sh.2^T : dsh [MT][32] -> d hc ; mask with hc -> dY of sh.0
+    mcn_zero<NI, MI>(acc);
+    mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_NSHP / 8, pk + (L.bC2 >> 2) + (wn * NI) * (MCN_NSHP / 8) * 64, lane);
+    __syncthreads();
+    mask_store<WIDTH, NI, MI>(acc, a.act_save + (size_t)(D + 1) * AS, a.dy_save + (size_t)(D + 1) * AS, X, XW, mrow0, ncol0, row0, total, lane);
+    __syncthreads();
+    // ---- sh.0^T and sigma.0^T both feed d h_{D-1}
+    mcn_zero<NI, MI>(acc);
+    mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, NSH, pk + (L.bC1 >> 2) + (wn * NI) * NSH * 64, lane);
+    __syncthreads();
+    {   // dY of sigma.0 = d sigma * w_sigma2 masked by hs > 0 (outer product, no GEMM); also d w_sigma2
+        const float* hs = a.act_save + (size_t)D * AS;
+        float* dys = a.dy_save + (size_t)D * AS;
+        const float* w2 = prm + L.pWs2;
+        constexpr int MG = 512 / W4;            // sample groups (512 threads / chunks per row)
+        const int c4 = tid % W4, mg = tid / W4;
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + 4 * c4);
+        f32x4 gw = {0.f, 0.f, 0.f, 0.f};
+        for (int m = mg; m < MT; m += MG) {
+            const bool ok = row0 + m < total;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+            if (ok) hv = *reinterpret_cast<const f32x4*>(hs + (size_t)(row0 + m) * WIDTH + 4 * c4);
+            const float ds = sdsig[m];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = hv[e] > 0.f ? ds * ww[e] : 0.f; gw[e] = fmaf(ds, hv[e], gw[e]); }
+            *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, c4, XW)]) = v;
+            if (ok) *reinterpret_cast<f32x4*>(dys + (size_t)(row0 + m) * WIDTH + 4 * c4) = v;
+        }
+        if (a.grads) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(a.grads + L.pWs2 + 4 * c4 + e, gw[e]);
+        }
+    }
+    __syncthreads();
+    mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, NSH, pk + (L.bS1 >> 2) + (wn * NI) * NSH * 64, lane);
+    __syncthreads();
+    mask_store<WIDTH, NI, MI>(acc, a.act_save + (size_t)(D - 1) * AS, a.dy_save + (size_t)(D - 1) * AS, X, XW, mrow0, ncol0, row0, total, lane);
+    __syncthreads();
+
+    // ---- trunk, last layer to first.  X holds dY_l; the encoded-input gradient accumulates in denc.
+    f32x16 denc[1][1];
+    mcn_zero<1, 1>(denc);
+    constexpr int ENC_TILES = 2 * (MT / 32);          // (2 k-tiles of the 64 encoded channels) x m-tiles
+    static_assert(ENC_TILES <= 16, "at most two encoded-gradient tiles per wave");
+    f32x16 denc2[1][1];                                // second tile when ENC_TILES > 8 (MT = 256)
+    mcn_zero<1, 1>(denc2);
+    for (int l = D - 1; l >= 0; --l) {
+        if (l == 0 || l == L.skip) {
+            const f32x4* pe = pk + ((l == 0 ? L.bEnc0 : L.bEncS) >> 2);
+            {
+                const int t = wave;
+                if (t < ENC_TILES) mcn_gemm_seg<1, 1>(denc, X, XW, (t >> 1) * 32, 0, NSH, pe + (t & 1) * NSH * 64, lane);
+            }
+            if (ENC_TILES > 8) {
+                const int t = wave + 8;
+                if (t < ENC_TILES) mcn_gemm_seg<1, 1>(denc2, X, XW, (t >> 1) * 32, 0, NSH, pe + (t & 1) * NSH * 64, lane);
+            }
+        }
+        if (l == 0) break;
+        mcn_zero<NI, MI>(acc);
+        mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, NSH, pk + (L.bH[l] >> 2) + (wn * NI) * NSH * 64, lane);
+        __syncthreads();
+        mask_store<WIDTH, NI, MI>(acc, a.act_save + (size_t)(l - 1) * AS, a.dy_save + (size_t)(l - 1) * AS, X, XW, mrow0, ncol0, row0, total, lane);
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- encoded-input gradient -> LDS [MT][64]
+    {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int t = wave + 8 * pass;
+            if (t < ENC_TILES) {
+                const int mt = t >> 1, kt = t & 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = pass == 0 ? denc[0][0][4 * q + e] : denc2[0][0][4 * q + e];
+                    *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(mt * 32 + r, (kt * 32 + 8 * q + 4 * h) >> 2, XW)]) = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- encoding backward -> d xyz -> d rays_o / d rays_d
+    //   enc channel 3+20c+f = w_f sin(2^f x_c), 3+20c+10+f = w_f cos(2^f x_c)  (w_f already inside enc_save)
+    if (a.d_rays_o || a.d_rays_d) {
+        for (int it = tid; it < MT * 3; it += 512) {
+            const int m = it / 3, c = it - m * 3;
+            const long long g = row0 + m;
+            if (g >= total) continue;
+            const float* en = a.enc_save + (size_t)g * MCN_ENCP;
+            float dx = X[mcn_swz(m, c, XW)];
+#pragma unroll
+            for (int f = 0; f < MCN_NFREQ; ++f) {
+                const float s = en[3 + 20 * c + f], co = en[3 + 20 * c + 10 + f];
+                const float ds = X[mcn_swz(m, 3 + 20 * c + f, XW)], dc = X[mcn_swz(m, 3 + 20 * c + 10 + f, XW)];
+                dx += (float)(1 << f) * (co * ds - s * dc);
+            }
+            const int ray = sray[m];
+            if (a.d_rays_o) atomicAdd(a.d_rays_o + ray * 3 + c, dx);
+            if (a.d_rays_d) atomicAdd(a.d_rays_d + ray * 3 + c, dx * sz[m] + sddir[m * 4 + c]);
+        }
+    }
+    // ---- d bias of sigma.2 = sum of d sigma over the tile
+    if (a.grads) {
+        float v = bs2_part;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) sred[wave] = v;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < 8; ++w) s += sred[w];
+            atomicAdd(a.grads + L.pBs2, s);
+        }
+    }
+}
+
+template <int WIDTH>
+static hipError_t launch_bwd(const McnMlpBwdArgs& a, long long max_rows, hipStream_t st) {
+    using SM = BwdSmem<WIDTH>;
+    const int grid = (int)((max_rows + SM::MT - 1) / SM::MT);
+    if (grid <= 0) return hipSuccess;
+    auto kern = mlp_bwd_kernel<WIDTH>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SM::bytes, st, a);
+    return hipGetLastError();
+}
+
+hipError_t mcn_launch_mlp_bwd(const McnMlpBwdArgs& a, hipStream_t st) {
+    const long long max_rows = a.count ? (long long)a.max_rows : (long long)a.n_rays * a.S;
+    switch (a.lay.width) {
+        case 256: return launch_bwd<256>(a, max_rows, st);
+        case 128: return launch_bwd<128>(a, max_rows, st);
+        case 64:  return launch_bwd<64>(a, max_rows, st);
+        case 32:  return launch_bwd<32>(a, max_rows, st);
+    }
+    return hipErrorInvalidValue;
+}

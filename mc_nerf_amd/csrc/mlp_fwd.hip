@@ -1,0 +1,285 @@
+// Fused NeRF MLP forward for gfx950: sample generation -> positional encoding -> trunk -> sigma / SH
+// heads -> SH colour -> sigmoid, one launch, activations never leave the CU (LDS + registers).
+//
+// Replaces (reference, eager PyTorch): NeRF_Model.inference's gather/encode/MLP/scatter part
+// (model/mc_nerf.py:688-701), SinCosEmbedding.forward (model/net_block.py:20-35),
+// CorseFine_NeRF.forward (model/net_block.py:67-78) and eval_sh (model/net_utils.py:103-191).
+//
+// One workgroup = 8 waves = one tile of MT samples.  Per layer each wave accumulates its
+// (NI x MI) 32x32 output tiles with v_mfma_f32_32x32x2_f32 (exact fp32), weight fragments streamed
+// from L2 in packed order, activation fragments read from the swizzled LDS tile; the layer output
+// (bias + ReLU) is written back in place after a barrier.
+#include "mcnerf_common.h"
+#include "mcnerf_kernels.h"
+
+template <int WIDTH>
+struct FwdSmem {
+    using G = McnGeom<WIDTH>;
+    static constexpr int MT = G::WM * G::MI * 32;
+    static constexpr int XW = WIDTH > 64 ? WIDTH : 64;
+    static constexpr int oX = 0;
+    static constexpr int oXyz = oX + MT * XW;          // [MT][4]  x,y,z,z_val
+    static constexpr int oDir = oXyz + MT * 4;         // [MT][4]  dx,dy,dz,-
+    static constexpr int oSig = oDir + MT * 4;         // [WN][MT] partial sigma
+    static constexpr int oSh = oSig + G::WN * MT;      // [MT][33] sh coefficients
+    static constexpr int oAddr = oSh + MT * 33;        // [MT] int: ray*S + j  (or -1)
+    static constexpr int total = oAddr + MT;
+    static constexpr size_t bytes = (size_t)total * 4;
+};
+
+// Writes the 63(+1 pad) encoded channels of every tile row into X columns 0..63 (swizzled).
+// Channel order (model/net_block.py:22-33): [x,y,z, per coord c: sin(2^f c) f=0..9, cos(2^f c) f=0..9],
+// each multiplied by the BARF weight of its frequency (all ones when BARF is off).
+template <int MT, int XW>
+__device__ __forceinline__ void write_encoding(float* X, const float* sxyz, const float* barf_w, int tid, int nthreads) {
+    for (int it = tid; it < MT * 30; it += nthreads) {
+        const int m = it / 30, cf = it - m * 30;
+        const int c = cf / 10, f = cf - c * 10;
+        const float v = sxyz[m * 4 + c] * (float)(1 << f);     // exact: power-of-two scale
+        float s, co;
+        sincosf(v, &s, &co);
+        const float w = barf_w[f];
+        X[mcn_swz(m, 3 + c * 20 + f, XW)] = s * w;
+        X[mcn_swz(m, 3 + c * 20 + 10 + f, XW)] = co * w;
+    }
+    for (int it = tid; it < MT * 4; it += nthreads) {
+        const int m = it >> 2, c = it & 3;
+        X[mcn_swz(m, c == 3 ? 63 : c, XW)] = (c == 3) ? 0.f : sxyz[m * 4 + c];
+    }
+}
+
+template <int WIDTH, bool SAVE>
+__global__ __launch_bounds__(512) void mlp_fwd_kernel(McnMlpFwdArgs a) {
+    using G = McnGeom<WIDTH>;
+    using SM = FwdSmem<WIDTH>;
+    constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN;
+    constexpr int KSH = WIDTH / 8;      // k-steps of a hidden segment
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem + SM::oX;
+    float* sxyz = smem + SM::oXyz;
+    float* sdir = smem + SM::oDir;
+    float* ssig = smem + SM::oSig;
+    float* ssh = smem + SM::oSh;
+    int* saddr = reinterpret_cast<int*>(smem + SM::oAddr);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int mrow0 = wm * MI * 32;
+    const int ncol0 = wn * NI * 32;
+    const long long total = a.count ? (long long)min(*a.count, a.max_rows) : (long long)a.n_rays * a.S;
+    const long long row0 = (long long)blockIdx.x * MT;
+    if (row0 >= total) return;
+    const McnLayout& L = a.lay;
+    const float* __restrict__ prm = a.params;
+    const f32x4* __restrict__ pk = reinterpret_cast<const f32x4*>(a.packed);
+
+    // ---- per-sample setup: position, direction, output address
+    for (int m = tid; m < MT; m += 512) {
+        const long long g = row0 + m;
+        float x = 0.f, y = 0.f, z = 0.f, dx = 0.f, dy = 0.f, dz = 1.f, zv = 0.f;
+        int addr = -1;
+        if (g < total) {
+            int ray, j;
+            if (a.idx) { const int2 rj = a.idx[g]; ray = rj.x; j = rj.y; }
+            else { ray = (int)(g / a.S); j = (int)(g - (long long)ray * a.S); }
+            zv = a.zgrid[j];
+            if (a.jitter) zv = __fadd_rn(zv, a.jitter[ray]);
+            dx = a.rays_d[ray * 3 + 0]; dy = a.rays_d[ray * 3 + 1]; dz = a.rays_d[ray * 3 + 2];
+            // o + d*z with separate roundings, as the reference's broadcasted mul then add (mc_nerf.py:602)
+            x = __fadd_rn(a.rays_o[ray * 3 + 0], __fmul_rn(dx, zv));
+            y = __fadd_rn(a.rays_o[ray * 3 + 1], __fmul_rn(dy, zv));
+            z = __fadd_rn(a.rays_o[ray * 3 + 2], __fmul_rn(dz, zv));
+            addr = ray * a.S + j;
+        }
+        sxyz[m * 4 + 0] = x; sxyz[m * 4 + 1] = y; sxyz[m * 4 + 2] = z; sxyz[m * 4 + 3] = zv;
+        sdir[m * 4 + 0] = dx; sdir[m * 4 + 1] = dy; sdir[m * 4 + 2] = dz; sdir[m * 4 + 3] = 0.f;
+        saddr[m] = addr;
+    }
+    __syncthreads();
+    write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, 512);
+    __syncthreads();
+    if (SAVE) {   // encoded inputs are the X operand of dW for layer 0 and the skip layer
+        for (int it = tid; it < MT * 16; it += 512) {
+            const int m = it >> 4, ch = it & 15;
+            if (row0 + m < total)
+                *reinterpret_cast<f32x4*>(a.enc_save + (size_t)(row0 + m) * MCN_ENCP + ch * 4) =
+                    *reinterpret_cast<const f32x4*>(&X[mcn_swz_chunk(m, ch, XW)]);
+        }
+    }
+
+    f32x16 acc[NI][MI];
+    // ---- trunk
+    for (int l = 0; l < L.depth; ++l) {
+        mcn_zero<NI, MI>(acc);
+        if (l == 0) {
+            mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_ENCP / 8, pk + (L.fEnc0 >> 2) + (wn * NI) * (MCN_ENCP / 8) * 64, lane);
+        } else {
+            mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, KSH, pk + (L.fH[l] >> 2) + (wn * NI) * KSH * 64, lane);
+            if (l == L.skip) {
+                __syncthreads();                       // everyone finished reading h from X
+                write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, 512);
+                __syncthreads();
+                mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_ENCP / 8, pk + (L.fEncS >> 2) + (wn * NI) * (MCN_ENCP / 8) * 64, lane);
+            }
+        }
+        __syncthreads();
+        const float* bias = prm + L.pB[l];
+        float* save = SAVE ? a.act_save + (size_t)l * a.act_stride : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n4 = ncol0 + ni * 32 + 8 * q + 4 * h;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n4);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int m = mrow0 + mi * 32 + r;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[ni][mi][4 * q + e] + bb[e], 0.f);
+                    *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, n4 >> 2, XW)]) = v;
+                    if (SAVE && row0 + m < total)
+                        *reinterpret_cast<f32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = v;
+                }
+            }
+        __syncthreads();
+    }
+
+    // ---- sigma head: hidden layer on MFMA, the 1-wide output layer lane-local on the VALU
+    {
+        mcn_zero<NI, MI>(acc);
+        mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, KSH, pk + (L.fS1 >> 2) + (wn * NI) * KSH * 64, lane);
+        const float* bias = prm + L.pBs1;
+        const float* w2 = prm + L.pWs2;
+        float* save = SAVE ? a.act_save + (size_t)L.depth * a.act_stride : nullptr;
+        float s[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) s[mi] = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n4 = ncol0 + ni * 32 + 8 * q + 4 * h;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n4);
+                const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + n4);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaxf(acc[ni][mi][4 * q + e] + bb[e], 0.f);
+                        s[mi] = fmaf(v[e], ww[e], s[mi]);
+                    }
+                    const int m = mrow0 + mi * 32 + r;
+                    if (SAVE && row0 + m < total)
+                        *reinterpret_cast<f32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = v;
+                }
+            }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            s[mi] += __shfl_xor(s[mi], 32);
+            if (h == 0) ssig[wn * MT + mrow0 + mi * 32 + r] = s[mi];
+        }
+    }
+    // ---- SH head hidden layer (reads the same trunk output still resident in X)
+    {
+        mcn_zero<NI, MI>(acc);
+        mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, KSH, pk + (L.fC1 >> 2) + (wn * NI) * KSH * 64, lane);
+        __syncthreads();
+        const float* bias = prm + L.pBc1;
+        float* save = SAVE ? a.act_save + (size_t)(L.depth + 1) * a.act_stride : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n4 = ncol0 + ni * 32 + 8 * q + 4 * h;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n4);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int m = mrow0 + mi * 32 + r;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[ni][mi][4 * q + e] + bb[e], 0.f);
+                    *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, n4 >> 2, XW)]) = v;
+                    if (SAVE && row0 + m < total)
+                        *reinterpret_cast<f32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = v;
+                }
+            }
+        __syncthreads();
+    }
+    // ---- SH output layer (27 -> 32 padded outputs): one 32-row m-tile per wave
+    for (int mt = wave; mt < MT / 32; mt += 8) {
+        f32x16 a1[1][1];
+        mcn_zero<1, 1>(a1);
+        mcn_gemm_seg<1, 1>(a1, X, XW, mt * 32, 0, KSH, pk + (L.fC2 >> 2), lane);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = (e & 3) + 8 * (e >> 2) + 4 * h;
+            ssh[(mt * 32 + r) * 33 + n] = a1[0][0][e];
+        }
+    }
+    __syncthreads();
+    // ---- per-sample epilogue: sigma, SH colour, sigmoid
+    for (int m = tid; m < MT; m += 512) {
+        const long long g = row0 + m;
+        if (g >= total) continue;
+        float sigma = prm[L.pBs2];
+#pragma unroll
+        for (int w = 0; w < WN; ++w) sigma += ssig[w * MT + m];
+        float sh[MCN_NSH];
+#pragma unroll
+        for (int i = 0; i < MCN_NSH; ++i) sh[i] = ssh[m * 33 + i] + prm[L.pBc2 + i];
+        float b[9];
+        mcn_sh_basis(sdir[m * 4 + 0], sdir[m * 4 + 1], sdir[m * 4 + 2], b);
+        f32x4 o;
+        o[0] = sigma;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float pre = b[0] * sh[9 * c];
+#pragma unroll
+            for (int i = 1; i < 9; ++i) pre += b[i] * sh[9 * c + i];
+            o[1 + c] = 1.0f / (1.0f + expf(-pre));
+        }
+        *reinterpret_cast<f32x4*>(a.out + (size_t)saddr[m] * 4) = o;
+        if (SAVE) {
+            float* dst = a.sh_save + (size_t)g * MCN_NSHP;
+#pragma unroll
+            for (int i = 0; i < MCN_NSH; ++i) dst[i] = sh[i];
+        }
+    }
+}
+
+template <int WIDTH>
+static hipError_t launch_fwd(const McnMlpFwdArgs& a, long long max_rows, hipStream_t st) {
+    using SM = FwdSmem<WIDTH>;
+    const int grid = (int)((max_rows + SM::MT - 1) / SM::MT);
+    if (grid <= 0) return hipSuccess;
+    const bool save = a.act_save != nullptr;
+    auto kern = save ? mlp_fwd_kernel<WIDTH, true> : mlp_fwd_kernel<WIDTH, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SM::bytes, st, a);
+    return hipGetLastError();
+}
+
+hipError_t mcn_launch_mlp_fwd(const McnMlpFwdArgs& a, hipStream_t st) {
+    const long long max_rows = a.count ? (long long)a.max_rows : (long long)a.n_rays * a.S;
+    switch (a.lay.width) {
+        case 256: return launch_fwd<256>(a, max_rows, st);
+        case 128: return launch_fwd<128>(a, max_rows, st);
+        case 64:  return launch_fwd<64>(a, max_rows, st);
+        case 32:  return launch_fwd<32>(a, max_rows, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+int mcn_mlp_tile_rows(int width) {
+    switch (width) {
+        case 256: return FwdSmem<256>::MT;
+        case 128: return FwdSmem<128>::MT;
+        case 64:  return FwdSmem<64>::MT;
+        case 32:  return FwdSmem<32>::MT;
+    }
+    return 0;
+}

@@ -1,0 +1,205 @@
+// (1) Weight-threshold fine-sample selection + compaction, entirely on the device:
+//     replaces nonzero / expand / arithmetic / index_put of model/mc_nerf.py:623-629, 692-694 and
+//     removes the reference's host syncs (.item(), nonzero).
+// (2) Per-pixel ray generation from one camera's world->cam pose and inverse intrinsics, forward and
+//     backward: replaces MC_Model.get_rays + generate_rand_rays (model/mc_nerf.py:124-145, 213-256,
+//     327-345) for the selected pixels only.
+#include "mcnerf_kernels.h"
+
+// ------------------------------------------------------------------ selection
+__device__ __forceinline__ float sel_threshold(const McnSelectArgs& a) {
+    // min(weight_thresh, weights.max()) (model/mc_nerf.py:623)
+    return fminf(a.thresh, __uint_as_float(*a.wmax_bits));
+}
+
+__global__ __launch_bounds__(256) void select_count_kernel(McnSelectArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const float thr = sel_threshold(a);
+    int cnt = 0;
+    for (int base = 0; base < a.Sc; base += 64) {
+        const int j = base + lane;
+        const bool sel = j < a.Sc && a.w_sel[(size_t)n * a.Sc + j] >= thr;
+        cnt += __popcll(__ballot(sel));
+    }
+    if (lane == 0) a.ray_counts[n] = cnt * a.scale;
+    if (a.out_f) {      // defaults for never-evaluated fine samples (model/mc_nerf.py:692-694)
+        const int Sf = a.Sc * a.scale;
+        f32x4 d; d[0] = a.sigma_default; d[1] = 1.f; d[2] = 1.f; d[3] = 1.f;
+        f32x4* o = reinterpret_cast<f32x4*>(a.out_f) + (size_t)n * Sf;
+        for (int j = lane; j < Sf; j += 64) o[j] = d;
+    }
+}
+
+// Exclusive scan of ray_counts -> ray_offsets, total -> *count.  One workgroup; N is at most ~1e6.
+__global__ __launch_bounds__(1024) void select_scan_kernel(McnSelectArgs a) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < a.N; base += 1024) {
+        const int i = base + tid;
+        const int v = i < a.N ? a.ray_counts[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wv; ++w) woff += wsum[w];
+        const int carry = carry_s;
+        if (i < a.N) a.ray_offsets[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) *a.count = carry_s;
+}
+
+__global__ __launch_bounds__(256) void select_write_kernel(McnSelectArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const float thr = sel_threshold(a);
+    int pos = a.ray_offsets[n];
+    for (int base = 0; base < a.Sc; base += 64) {
+        const int j = base + lane;
+        const bool sel = j < a.Sc && a.w_sel[(size_t)n * a.Sc + j] >= thr;
+        const unsigned long long m = __ballot(sel);
+        if (sel) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            int2* dst = a.idx + pos + rank * a.scale;
+            for (int r = 0; r < a.scale; ++r) dst[r] = make_int2(n, j * a.scale + r);
+        }
+        pos += __popcll(m) * a.scale;
+    }
+}
+
+hipError_t mcn_launch_select(const McnSelectArgs& a, hipStream_t st) {
+    if (a.N <= 0) return hipSuccess;
+    const dim3 g((a.N + 3) / 4), b(256);
+    hipLaunchKernelGGL(select_count_kernel, g, b, 0, st, a);
+    hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(select_write_kernel, g, b, 0, st, a);
+    return hipGetLastError();
+}
+
+// Keeps idx_in[perm[i]], i < keep: the random cap of model/mc_nerf.py:630-632.
+__global__ void cap_gather_kernel(const int2* idx_in, const long long* perm, int keep, int2* idx_out, int* count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < keep) idx_out[i] = idx_in[perm[i]];
+    if (i == 0) *count = keep;
+}
+hipError_t mcn_launch_cap_gather(const int2* idx_in, const long long* perm, int keep, int2* idx_out, int* count, hipStream_t st) {
+    if (keep <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cap_gather_kernel, dim3((keep + 255) / 256), dim3(256), 0, st, idx_in, perm, keep, idx_out, count);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ ray generation
+// d = normalize(R^T K^-1 [u+.5, v+.5, 1]^T), o = -R^T t, following the reference's op order
+// (pix @ K^-T, lift, @ pose_inv^T, minus origin, normalise) so results agree to ~1e-7.
+__global__ __launch_bounds__(256) void raygen_fwd_kernel(McnRaygenArgs a) {
+    __shared__ float P[12], K[9];
+    if (threadIdx.x < 12) P[threadIdx.x] = a.pose[threadIdx.x];
+    if (threadIdx.x < 9) K[threadIdx.x] = a.kinv[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const long long pid = a.pix[i];
+    const float u = (float)(pid % a.W) + 0.5f, v = (float)(pid / a.W) + 0.5f;
+    float cam[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cam[r] = __fadd_rn(__fadd_rn(__fmul_rn(u, K[r * 3]), __fmul_rn(v, K[r * 3 + 1])), K[r * 3 + 2]);
+    float d[3], o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        // pose_inv row c = [R[0][c], R[1][c], R[2][c], -(R^T t)[c]]
+        const float ti = -(__fadd_rn(__fadd_rn(__fmul_rn(P[0 * 4 + c], P[3]), __fmul_rn(P[1 * 4 + c], P[7])), __fmul_rn(P[2 * 4 + c], P[11])));
+        const float w = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(cam[0], P[0 * 4 + c]), __fmul_rn(cam[1], P[1 * 4 + c])), __fmul_rn(cam[2], P[2 * 4 + c])), ti);
+        o[c] = ti;
+        d[c] = __fsub_rn(w, ti);
+    }
+    const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.rays_d[i * 3 + c] = d[c] / nrm; a.rays_o[i * 3 + c] = o[c]; }
+}
+
+hipError_t mcn_launch_raygen_fwd(const McnRaygenArgs& a, hipStream_t st) {
+    if (a.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(raygen_fwd_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// Backward: accumulates d_pose[3][4] and d_kinv[3][3] over the n rays (block reduction + one atomic
+// per block and value).
+__global__ __launch_bounds__(256) void raygen_bwd_kernel(McnRaygenBwdArgs a) {
+    __shared__ float P[12], K[9];
+    __shared__ float red[4][24];
+    if (threadIdx.x < 12) P[threadIdx.x] = a.pose[threadIdx.x];
+    if (threadIdx.x < 9) K[threadIdx.x] = a.kinv[threadIdx.x];
+    __syncthreads();
+    float acc[21];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) acc[k] = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+        const long long pid = a.pix[i];
+        const float p[3] = {(float)(pid % a.W) + 0.5f, (float)(pid / a.W) + 0.5f, 1.f};
+        float cam[3], q[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cam[r] = p[0] * K[r * 3] + p[1] * K[r * 3 + 1] + K[r * 3 + 2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[c] = cam[0] * P[c] + cam[1] * P[4 + c] + cam[2] * P[8 + c];
+        const float inv = 1.f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        const float gd[3] = {a.d_rays_d[i * 3], a.d_rays_d[i * 3 + 1], a.d_rays_d[i * 3 + 2]};
+        const float dn[3] = {q[0] * inv, q[1] * inv, q[2] * inv};
+        const float dot = dn[0] * gd[0] + dn[1] * gd[1] + dn[2] * gd[2];
+        float gq[3], gcam[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gq[c] = (gd[c] - dn[c] * dot) * inv;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            gcam[j] = P[j * 4] * gq[0] + P[j * 4 + 1] * gq[1] + P[j * 4 + 2] * gq[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[j * 3 + c] += cam[j] * gq[c];        // dR[j][c] from the direction
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[9 + j * 3 + k] += gcam[j] * p[k];     // dKinv[j][k]
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[18 + c] += a.d_rays_o[i * 3 + c];         // sum of origin gradients
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 21) {
+        const int k = threadIdx.x;
+        const float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        if (k < 9) atomicAdd(&a.d_pose[(k / 3) * 4 + (k % 3)], v);
+        else if (k < 18) atomicAdd(&a.d_kinv[k - 9], v);
+        else {
+            // o_c = -sum_j R[j][c] t_j:  dR[j][c] += -t_j * Go_c ;  dt_j = -sum_c R[j][c] Go_c
+            const int c = k - 18;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                atomicAdd(&a.d_pose[j * 4 + c], -P[j * 4 + 3] * v);
+                atomicAdd(&a.d_pose[j * 4 + 3], -P[j * 4 + c] * v);
+            }
+        }
+    }
+}
+
+hipError_t mcn_launch_raygen_bwd(const McnRaygenBwdArgs& a, hipStream_t st) {
+    if (a.n <= 0) return hipSuccess;
+    int grid = (a.n + 255) / 256;
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(raygen_bwd_kernel, dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}

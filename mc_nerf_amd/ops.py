@@ -1,0 +1,215 @@
+"""Tensor-level wrappers over the C ABI (include/mcnerf.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every function below
+checks its tensors (device, dtype, contiguity), passes raw pointers to libmcnerf.so and returns
+tensors.  All launches go to ``torch.cuda.current_stream()``.  There is no CPU path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+
+
+@dataclass(frozen=True)
+class Net:
+    """(depth, width, skip) of one CorseFine_NeRF (model/net_block.py:40-49 in the reference)."""
+    depth: int
+    width: int
+    skip: int
+
+    @property
+    def triple(self):
+        return (self.depth, self.width, self.skip)
+
+    def in_features(self, i: int) -> int:
+        if i == 0:
+            return 63
+        return self.width + 63 if i == self.skip else self.width
+
+    def shapes(self):
+        """Tensor shapes in the reference's state-dict order."""
+        s = []
+        for i in range(self.depth):
+            s += [(self.width, self.in_features(i)), (self.width,)]
+        s += [(self.width, self.width), (self.width,), (1, self.width), (1,),
+              (self.width, self.width), (self.width,), (27, self.width), (27,)]
+        return s
+
+    def names(self):
+        n = []
+        for i in range(self.depth):
+            n += [f"xyz_encoding_{i+1}.0.weight", f"xyz_encoding_{i+1}.0.bias"]
+        n += ["sigma.0.weight", "sigma.0.bias", "sigma.2.weight", "sigma.2.bias",
+              "sh.0.weight", "sh.0.bias", "sh.2.weight", "sh.2.bias"]
+        return n
+
+
+def param_count(net: Net) -> int:
+    return int(_lib.lib().mcnerf_param_count(*net.triple))
+
+
+def packed_count(net: Net) -> int:
+    return int(_lib.lib().mcnerf_packed_count(*net.triple))
+
+
+def param_offsets(net: Net):
+    import ctypes
+    n = 2 * net.depth + 8
+    arr = (ctypes.c_longlong * n)()
+    _lib.call("mcnerf_param_offsets", *net.triple, ctypes.cast(arr, ctypes.c_void_p))
+    return [int(v) for v in arr]
+
+
+def tile_rows(width: int) -> int:
+    return int(_lib.lib().mcnerf_tile_rows(width))
+
+
+# --------------------------------------------------------------------------- helpers
+def _p(t: Optional[Tensor], dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.McnerfError("mc_nerf_amd ops need CUDA/HIP tensors (no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.McnerfError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.McnerfError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def flatten_params(net: Net, tensors, device) -> Tensor:
+    """Copies per-tensor parameters (reference order) into a fresh flat buffer."""
+    flat = torch.zeros(param_count(net), dtype=torch.float32, device=device)
+    for off, shp, t in zip(param_offsets(net), net.shapes(), tensors):
+        n = 1
+        for d in shp:
+            n *= d
+        flat[off:off + n].copy_(t.reshape(-1))
+    return flat
+
+
+# --------------------------------------------------------------------------- ops
+def pack_weights(net: Net, params: Tensor, packed: Optional[Tensor] = None) -> Tensor:
+    if packed is None:
+        packed = torch.empty(packed_count(net), dtype=torch.float32, device=params.device)
+    _lib.call("mcnerf_pack_weights", *net.triple, _p(params), _p(packed), _stream())
+    return packed
+
+
+def raygen_fwd(pose: Tensor, kinv: Tensor, pix: Tensor, W: int) -> Tuple[Tensor, Tensor]:
+    n = pix.numel()
+    d = torch.empty(n, 3, dtype=torch.float32, device=pix.device)
+    o = torch.empty_like(d)
+    _lib.call("mcnerf_raygen_fwd", _p(pose), _p(kinv), _p(pix, torch.int64), n, W, _p(d), _p(o), _stream())
+    return d, o
+
+
+def raygen_bwd(pose: Tensor, kinv: Tensor, pix: Tensor, W: int, d_d: Tensor, d_o: Tensor) -> Tuple[Tensor, Tensor]:
+    d_pose = torch.zeros(3, 4, dtype=torch.float32, device=pix.device)
+    d_kinv = torch.zeros(3, 3, dtype=torch.float32, device=pix.device)
+    _lib.call("mcnerf_raygen_bwd", _p(pose), _p(kinv), _p(pix, torch.int64), pix.numel(), W,
+              _p(d_d), _p(d_o), _p(d_pose), _p(d_kinv), _stream())
+    return d_pose, d_kinv
+
+
+@dataclass
+class MlpSave:
+    """Workspaces written by mlp_fwd(save=True) and consumed by mlp_bwd / mlp_dw."""
+    capacity: int
+    act: Tensor
+    enc: Tensor
+    sh: Tensor
+
+
+def alloc_save(net: Net, capacity: int, device) -> MlpSave:
+    capacity = max(int(capacity), 1)
+    return MlpSave(capacity,
+                   torch.empty((net.depth + 2) * capacity * net.width, dtype=torch.float32, device=device),
+                   torch.empty(capacity * 64, dtype=torch.float32, device=device),
+                   torch.empty(capacity * 32, dtype=torch.float32, device=device))
+
+
+def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, zgrid: Tensor,
+            jitter: Optional[Tensor], barf_w: Tensor, out: Tensor, idx: Optional[Tensor] = None,
+            count: Optional[Tensor] = None, max_rows: int = 0, save: Optional[MlpSave] = None) -> None:
+    n_rays, S = rays_d.shape[0], zgrid.numel()
+    assert out.numel() == n_rays * S * 4
+    _lib.call("mcnerf_mlp_fwd", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
+              _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
+              _p(out), _p(save.act) if save else None, save.capacity if save else 0,
+              _p(save.enc) if save else None, _p(save.sh) if save else None, _stream())
+
+
+def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, zgrid: Tensor,
+            jitter: Optional[Tensor], barf_w: Tensor, out: Tensor, d_out: Tensor, save: MlpSave,
+            grads: Optional[Tensor], dy: Tensor, dsh: Tensor, d_rays_o: Optional[Tensor], d_rays_d: Optional[Tensor],
+            idx: Optional[Tensor] = None, count: Optional[Tensor] = None, max_rows: int = 0) -> None:
+    n_rays, S = rays_d.shape[0], zgrid.numel()
+    _lib.call("mcnerf_mlp_bwd", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
+              _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
+              _p(out), _p(d_out), _p(save.act), save.capacity, _p(save.enc), _p(save.sh),
+              _p(grads), _p(dy), _p(dsh), _p(d_rays_o), _p(d_rays_d), _stream())
+
+
+def mlp_dw(net: Net, save: MlpSave, dy: Tensor, dsh: Tensor, grads: Tensor, rows: int,
+           count: Optional[Tensor] = None) -> None:
+    _lib.call("mcnerf_mlp_dw", *net.triple, _p(count, torch.int32), int(rows), _p(save.act), _p(save.enc),
+              _p(dy), _p(dsh), save.capacity, _p(grads), _stream())
+
+
+def composite_fwd(sig_rgb: Tensor, rays_d: Tensor, zgrid: Tensor, jitter: Optional[Tensor], eps: Tensor,
+                  eps_sel: Optional[Tensor] = None, white_back: bool = True, want_depth: bool = False):
+    """-> rgb [N,3], depth [N,1] | None, opacity [N,1] | None, w_sel [N,S] | None, wmax_bits | None"""
+    N, S = rays_d.shape[0], zgrid.numel()
+    dev = rays_d.device
+    rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(N, 1, dtype=torch.float32, device=dev) if want_depth else None
+    opac = torch.empty(N, 1, dtype=torch.float32, device=dev) if want_depth else None
+    w_sel = torch.empty(N, S, dtype=torch.float32, device=dev) if eps_sel is not None else None
+    wmax = torch.zeros(1, dtype=torch.int32, device=dev) if eps_sel is not None else None
+    _lib.call("mcnerf_composite_fwd", _p(sig_rgb), _p(rays_d), _p(zgrid), _p(jitter), _p(eps), _p(eps_sel), N, S,
+              int(bool(white_back)), _p(rgb), _p(depth), _p(opac), _p(w_sel), _p(wmax, torch.int32), _stream())
+    return rgb, depth, opac, w_sel, wmax
+
+
+def composite_bwd(sig_rgb: Tensor, zgrid: Tensor, jitter: Optional[Tensor], eps: Tensor, d_rgb: Tensor,
+                  white_back: bool = True) -> Tensor:
+    N, S = d_rgb.shape[0], zgrid.numel()
+    d = torch.empty(N, S, 4, dtype=torch.float32, device=d_rgb.device)
+    _lib.call("mcnerf_composite_bwd", _p(sig_rgb), _p(zgrid), _p(jitter), _p(eps), _p(d_rgb), N, S,
+              int(bool(white_back)), _p(d), _stream())
+    return d
+
+
+def select_fine(w_sel: Tensor, wmax: Tensor, thresh: float, scale: int, sigma_default: float,
+                prefill: bool = True):
+    """-> idx [N*Sc*scale,2] int32 (first *count rows valid), count [1] int32, out_f [N,Sf,4] | None"""
+    N, Sc = w_sel.shape
+    dev = w_sel.device
+    idx = torch.empty(N * Sc * scale, 2, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    rc = torch.empty(N, dtype=torch.int32, device=dev)
+    ro = torch.empty(N, dtype=torch.int32, device=dev)
+    out_f = torch.empty(N, Sc * scale, 4, dtype=torch.float32, device=dev) if prefill else None
+    _lib.call("mcnerf_select_fine", _p(w_sel), _p(wmax, torch.int32), float(thresh), N, Sc, scale,
+              float(sigma_default), _p(rc, torch.int32), _p(ro, torch.int32), _p(idx, torch.int32),
+              _p(count, torch.int32), _p(out_f), _stream())
+    return idx, count, out_f
+
+
+def cap_gather(idx: Tensor, perm: Tensor, keep: int):
+    idx2 = torch.empty(keep, 2, dtype=torch.int32, device=idx.device)
+    count = torch.empty(1, dtype=torch.int32, device=idx.device)
+    _lib.call("mcnerf_cap_gather", _p(idx, torch.int32), _p(perm, torch.int64), int(keep), _p(idx2, torch.int32),
+              _p(count, torch.int32), _stream())
+    return idx2, count
