@@ -1,0 +1,360 @@
+"""MI355X-native counterparts of the reference's ``model/mc_nerf.py`` classes.
+
+``MC_Model`` / ``NeRF_Model`` keep the reference's constructor (`sys_param` dict), call signatures,
+attribute names, parameter names and checkpoint format, so the reference's
+``main.py`` train / demo loop can drive them unchanged; the volumetric rendering underneath is the
+HIP path of ``libmcnerf.so`` (no eager ATen ops, no host syncs on the train path for configs where
+the 128-per-ray cap cannot bind).
+
+Reference line numbers below are into the reference's ``model/mc_nerf.py`` unless stated otherwise.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from pathlib import Path
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.distributed as dist
+
+from .. import ops
+from .net_block import CorseFine_NeRF, SinCosEmbedding
+from .render import RaygenFn, RenderSettings, RenderTrainFn, render_test
+
+
+def _rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+# ============================================================================ renderer
+class NeRF_Model(nn.Module):
+    """Renderer (reference :543-867).  forward(rays_d, rays_o, epoch, step_r) -> (rgb_c, rgb_f) in
+    training mode, forward(rays_d, rays_o) -> (rgb, depth, opacity) otherwise (:586-596)."""
+
+    def __init__(self, sys_param):
+        logging.info("Creating NeRF Model (HIP / gfx950)...")
+        super().__init__()
+        self.sys_param = sys_param
+        self.mode = sys_param["mode"]
+        self.device = sys_param["device_type"]
+        self.near = sys_param["near"]
+        self.far = sys_param["far"]
+        self.samples_c = sys_param["samples"]
+        self.sample_scale = sys_param["scale"]
+        self.samples_f = self.samples_c * self.sample_scale
+        self.dim_sh = 3 * (sys_param["MLP_deg"] + 1) ** 2
+        self.white_back = sys_param["white_back"]
+        self.weights_pth = sys_param.get("root_weight", "./weights")
+        self.train_img_pth = sys_param.get("demo_render_pth", "./results")
+        self.batch_test = sys_param["batch"]
+        self.sigma_default = sys_param["sigma_default"]
+        self.weight_thresh = sys_param["sample_weight_thresh"]
+        self.render_h = sys_param.get("res_h", 800)
+        self.render_w = sys_param.get("res_w", 800)
+        self.data_name = sys_param.get("data_name", "scene")
+        # identical to the reference's grids (:570-571): fp32 torch.linspace on the target device
+        self.z_vals_c = torch.linspace(self.near, self.far, self.samples_c, device=self.device)
+        self.z_vals_f = torch.linspace(self.near, self.far, self.samples_f, device=self.device)
+        self.global_step = 0
+        self.emmbedding_xyz = SinCosEmbedding(sys_param)
+        self.nerf_coarse = CorseFine_NeRF(sys_param, type="coarse")
+        self.nerf_fine = CorseFine_NeRF(sys_param, type="fine")
+        self.settings = RenderSettings(self.samples_c, self.sample_scale, float(self.weight_thresh),
+                                       float(self.sigma_default), bool(self.white_back))
+        self.last_selection = None
+        self.last_flat_grads = None
+        if self.mode != 0:
+            self.nerf_ckpt_name = sys_param["demo_ckpt"]
+            ckpt = torch.load(Path(self.nerf_ckpt_name), map_location=self.device)
+            self.nerf_coarse.load_state_dict(self.rewrite_nerf_ckpt(ckpt, coarse=True))
+            self.nerf_fine.load_state_dict(self.rewrite_nerf_ckpt(ckpt))
+            logging.info("Loading weights:{}".format(self.nerf_ckpt_name))
+
+    # ------------------------------------------------------------------ API (:586-596)
+    def forward(self, *args):
+        self.global_step += 1
+        if self.mode == 0:
+            rays_d, rays_o, cur_epoch, step_r = args
+            rgb_c, rgb_f = self.render_rays_train(rays_d, rays_o, cur_epoch, step_r, only_coarse=False)
+            return rgb_c, rgb_f
+        rays_d, rays_o = args
+        return self.render_rays_test(rays_d, rays_o, self.nerf_coarse, self.nerf_fine)
+
+    def _dev(self, t):
+        return t.to(device=self.z_vals_c.device, dtype=torch.float32)
+
+    def render_rays_train(self, rays_d, rays_o, cur_epoch, step_r, only_coarse=False, *,
+                          jitter=None, eps_c=None, eps_sel=None, eps_f=None, cap_perm=None):
+        """Reference :598-646.  The keyword-only tensors are the reference's random draws
+        (U(0,(far-near)/Sc) per ray; three N(0,1) tensors; the cap permutation); when omitted they are
+        drawn from torch's device generator in the reference's order."""
+        N, dev = rays_d.shape[0], rays_d.device
+        if jitter is None:
+            jitter = torch.empty(N, 1, device=dev).uniform_(0.0, (self.far - self.near) / self.samples_c)
+        if eps_c is None:
+            eps_c = torch.randn(N, self.samples_c, device=dev)
+        if not only_coarse:
+            if eps_sel is None:
+                eps_sel = torch.randn(N, self.samples_c, device=dev)
+            if eps_f is None:
+                eps_f = torch.randn(N, self.samples_f, device=dev)
+        params = self.nerf_coarse.ordered_parameters() + self.nerf_fine.ordered_parameters()
+        self.nerf_coarse.flat_params()
+        self.nerf_fine.flat_params()
+        rgb_c, rgb_f, depth_c = RenderTrainFn.apply(self, self.nerf_coarse, self.nerf_fine, step_r, only_coarse,
+                                                    self._dev(jitter), self._dev(eps_c).contiguous(),
+                                                    None if eps_sel is None else self._dev(eps_sel).contiguous(),
+                                                    None if eps_f is None else self._dev(eps_f).contiguous(),
+                                                    cap_perm, rays_d, rays_o, *params)
+        if only_coarse:
+            return rgb_c, None, depth_c
+        return rgb_c, rgb_f
+
+    @torch.no_grad()
+    def render_rays_test(self, rays_d, rays_o, model_coarse, model_fine, *, eps_c=None, eps_sel=None, eps_f=None):
+        """Reference :648-680 (the nets are arguments because valid_train passes freshly loaded ones)."""
+        N, dev = rays_d.shape[0], rays_d.device
+        if eps_c is None:
+            eps_c = torch.randn(N, self.samples_c, device=dev)
+        if eps_sel is None:
+            eps_sel = torch.randn(N, self.samples_c, device=dev)
+        if eps_f is None:
+            eps_f = torch.randn(N, self.samples_f, device=dev)
+        return render_test(self, model_coarse, model_fine, rays_d.float(), rays_o.float(),
+                           self._dev(eps_c).contiguous(), self._dev(eps_sel).contiguous(), self._dev(eps_f).contiguous())
+
+    # ------------------------------------------------------------------ checkpoints (:738-752, 815-837)
+    def save_model(self, model, epoch):
+        save_path = os.path.join(Path(self.weights_pth), Path("train"))
+        os.makedirs(save_path, exist_ok=True)
+        stamp = time.strftime("%Y-%m-%d-%H-%M-%S", time.localtime())
+        name = "{}-EPOCH-{}-{}.ckpt".format(self.data_name, epoch, stamp)
+        self.ckpt_path = os.path.join(save_path, name)
+        if _rank() == 0:
+            module = model.module if hasattr(model, "module") else model
+            torch.save({"model_nerf": module.state_dict()}, self.ckpt_path)
+            logging.info("Save EPOCH {} weights: {}".format(epoch, self.ckpt_path))
+        return self.ckpt_path
+
+    @staticmethod
+    def rewrite_nerf_ckpt(ckpt, coarse=False):
+        """{'model_nerf': MC_Model.state_dict()} -> state dict of one net (prefix stripping)."""
+        prefix = "nerf.nerf_coarse." if coarse else "nerf.nerf_fine."
+        out = {}
+        for k, v in ckpt["model_nerf"].items():
+            if k.startswith(prefix):
+                out[k[len(prefix):]] = v
+        return out
+
+    @staticmethod
+    def cal_psnr(pred, gt):
+        return -10.0 * torch.log10(torch.mean((pred - gt) ** 2))
+
+    @torch.no_grad()
+    def valid_train(self, epoch, rays_valid, epoch_type=None):
+        """Chunked render of one validation view with the current weights (reference :754-813 renders
+        with weights re-loaded from the checkpoint just written; the values are identical).
+        Returns (rgb [HW,3], psnr) on rank 0, None elsewhere; other ranks wait at the barrier."""
+        result = None
+        if _rank() == 0:
+            rays_d, rays_o, gt = rays_valid
+            gt = gt.reshape(-1, 3)
+            chunks = []
+            for i in range(0, rays_d.shape[0], self.batch_test):
+                rgb, _, _ = self.render_rays_test(rays_d[i:i + self.batch_test], rays_o[i:i + self.batch_test],
+                                                  self.nerf_coarse, self.nerf_fine)
+                chunks.append(rgb)
+            rgb = torch.cat(chunks, 0)
+            psnr = self.cal_psnr(rgb, gt.to(rgb.device))
+            logging.info("EPOCH {} validation PSNR: {:.3f}".format(epoch, float(psnr)))
+            result = (rgb, psnr)
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+        return result
+
+
+# ============================================================================ multi-camera model
+class MC_Model(nn.Module):
+    """Camera parametrisation + ray generation + renderer (reference :24-540).
+
+    Train call:  model(data, epoch, epoch_type, cur_ratio) -> (loss_dict, intr_show, pose_show, rays_valid)
+    Demo call:   model(img_idx) -> (rgbs, depth, opacity) on the CPU, chunked by ``batch`` (:106-122).
+    """
+
+    def __init__(self, sys_param):
+        logging.info("Creating MC-NeRF Model (HIP / gfx950)...")
+        super().__init__()
+        self.sys_param = sys_param
+        self.mode = sys_param["mode"]
+        self.device = sys_param["device_type"]
+        self.batch = sys_param["batch"]
+        self.intr = sys_param["intr_mat"]
+        self.intr_inv = sys_param["intr_mat_inv"]
+        self.intr_train, self.intr_test, self.intr_val = self.intr
+        self.intr_train_inv, self.intr_test_inv, self.intr_val_inv = self.intr_inv
+        self.gt_pose = sys_param["gt_pose"].to(self.device)
+        self.test_pose = sys_param["test_pose"].to(self.device)
+        self.valid_pose = sys_param["valid_pose"].to(self.device)
+        self.valid_rgbs = sys_param["valid_rgbs"].to(self.device)
+        self.img_h = sys_param["data_img_h"]
+        self.img_w = sys_param["data_img_w"]
+        self.data_name = sys_param.get("data_name", "scene")
+        self.data_numb = sys_param["data_numb"]
+        self.train_numb, self.test_numb, self.val_numb = self.data_numb
+        self.register_parameters()
+        self.nerf = NeRF_Model(sys_param).to(self.device)
+        self.count_rays = 0
+        self.opt_idx = 0
+        self.last_epoch_type = 0
+
+    # ------------------------------------------------------------------ parameters (:347-371)
+    def register_parameters(self):
+        C, dev = self.train_numb, self.device
+        for name, shape in (("weights_pose", (C, 6)), ("weights_pose_intr", (C, 6)), ("weights_ux", (C,)),
+                            ("weights_uy", (C,)), ("weights_fx", (C,)), ("weights_fy", (C,))):
+            self.register_parameter(name, nn.Parameter(torch.ones(shape, device=dev), requires_grad=True))
+
+    # ------------------------------------------------------------------ forward (:58-122)
+    def forward(self, *args):
+        if self.sys_param["mode"] == 0:
+            return self._forward_train(*args)
+        return self._forward_demo(args[0] if len(args) == 1 else args)
+
+    def _forward_train(self, data, epoch, epoch_type, cur_ratio):
+        cam = int(data[1].reshape(-1)[0])          # read the camera id on the host side, before the H2D copy
+        gt_rgbs, img_id, intr_wpts, intr_pts, extr_wpts, extr_pts = [t.to(self.device) for t in data]
+        loss_dict = {}
+        emb = self.nerf.emmbedding_xyz
+        if epoch_type == "CAM_PARAM_EPOCH":
+            emb.barf_mode = False
+            self.intr_adj, self.pose_adj, self.calib_pose_adj = self.add_weights2param(True, True, True)
+            loss_dict["intr"] = [self.get_reproject_pixels(intr_wpts, self.intr_adj, self.calib_pose_adj), intr_pts]
+            loss_dict["extr"] = [self.get_reproject_pixels(extr_wpts, self.intr_adj, self.pose_adj), extr_pts]
+            self.opt_idx = 0
+        else:
+            joint = epoch_type == "GLOBAL_OPTIM_EPOCH"
+            emb.barf_mode = joint                                   # :74 / :86
+            self.intr_adj, self.pose_adj, self.calib_pose_adj = self.add_weights2param(True, joint, True)
+            loss_dict["intr"] = [self.get_reproject_pixels(intr_wpts, self.intr_adj, self.calib_pose_adj), intr_pts]
+            kinv = self.inverse_intrinsic(self.intr_adj[cam:cam + 1])[0]
+            # pixel subset first (same device randperm as :329), rays only for those pixels
+            rand_idx = torch.randperm(self.img_h * self.img_w, device=self.device)[: self.batch]
+            rays_d, rays_o = RaygenFn.apply(self.pose_adj[cam], kinv, rand_idx, self.img_w)
+            rgbs_c, rgbs_f = self.nerf(rays_d, rays_o, epoch, cur_ratio if joint else 1)
+            loss_dict["rgb"] = [rgbs_c, rgbs_f, gt_rgbs.reshape(-1, 3)[rand_idx]]
+            self.opt_idx = 1 if joint else 2
+        # validation rays of the same index, every step, as the reference (:97-99)
+        with torch.no_grad():
+            rays_dv, rays_ov = self.get_rays(self.valid_pose, cam, self.intr_val_inv.to(self.device))
+            rays_valid = [rays_dv, rays_ov, self.valid_rgbs[img_id].detach()]
+        intr_show = [self.intr_train.to(self.device).detach(), self.intr_adj.detach()]
+        pose_show = [self.gt_pose.detach(), self.pose_adj.detach()]
+        self.last_epoch_type = epoch_type
+        return loss_dict, intr_show, pose_show, rays_valid
+
+    @torch.no_grad()
+    def _forward_demo(self, img_id):
+        rays_d, rays_o = self.get_rays(self.test_pose, img_id, self.intr_test_inv.to(self.device))
+        rgbs, depth, opacity = [], [], []
+        for i in range(0, rays_d.shape[0], self.batch):
+            r, d, o = self.nerf(rays_d[i:i + self.batch], rays_o[i:i + self.batch])
+            rgbs.append(r.cpu()); depth.append(d.cpu()); opacity.append(o.cpu())
+        return torch.cat(rgbs, 0), torch.cat(depth, 0), torch.cat(opacity, 0)
+
+    # ------------------------------------------------------------------ rays (:124-145, 327-345)
+    def get_rays(self, pose, img_id, intr_inv):
+        """All H*W rays of camera ``img_id`` (row-major pixel centres), differentiable wrt the
+        selected pose and inverse intrinsics."""
+        cam = int(torch.as_tensor(img_id).reshape(-1)[0])
+        pix = torch.arange(self.img_h * self.img_w, device=self.device)
+        return RaygenFn.apply(pose[cam].to(self.device), intr_inv[cam].to(self.device), pix, self.img_w)
+
+    def generate_rand_rays(self, rays_d, rays_o, rand=True):
+        if rand:
+            idx = torch.randperm(rays_d.shape[0], device=rays_d.device)[: self.batch]
+        else:
+            start = (self.count_rays * self.batch) % rays_d.shape[0]
+            idx = torch.arange(start, min(start + self.batch, rays_d.shape[0]), device=rays_d.device)
+        self.count_rays += 1
+        return rays_d[idx], rays_o[idx], idx
+
+    # ------------------------------------------------------------------ camera parametrisation (:155-210, 269-316)
+    # Stock PyTorch for now (a fused kernel for this branch is the next widening step).
+    def add_weights2param(self, intr=True, extr=True, calib_extr=False):
+        return (self.add_weights2intr(self.img_h, self.img_w, adj=intr), self.add_weights2pose(adj=extr),
+                self.add_weights2calib_pose(adj=calib_extr))
+
+    def add_weights2intr(self, img_h, img_w, adj=True):
+        w = [self.weights_fx, self.weights_fy, self.weights_ux, self.weights_uy]
+        if not adj:
+            w = [t.detach() for t in w]
+        C = self.train_numb
+        K = torch.zeros(C, 3, 3, device=self.device)
+        # note: the reference scales fy by the image WIDTH as well (:172-173)
+        K[:, 0, 0] = torch.abs(float(img_w) * w[0])
+        K[:, 1, 1] = torch.abs(float(img_w) * w[1])
+        K[:, 0, 2] = torch.abs(float(img_w) / 2 * w[2])
+        K[:, 1, 2] = torch.abs(float(img_h) / 2 * w[3])
+        K[:, 2, 2] = 1.0
+        return K
+
+    def add_weights2pose(self, adj=True):
+        return self.se3_to_SE3(self.weights_pose if adj else self.weights_pose.detach())
+
+    def add_weights2calib_pose(self, adj=True):
+        return self.se3_to_SE3(self.weights_pose_intr if adj else self.weights_pose_intr.detach())
+
+    def inverse_intrinsic(self, intr_mats):
+        return torch.linalg.inv(intr_mats)
+
+    @staticmethod
+    def _series(theta, first_factor, nth=10):
+        """sum_i (-1)^i theta^(2i) / denom_i with denom_0 = first_factor and
+        denom_i = denom_{i-1} * (2i+a)(2i+a+1): the Taylor series A, B, C of :291-316."""
+        a = {1.0: 0, 2.0: 1, 6.0: 2}[first_factor]
+        ans = torch.zeros_like(theta)
+        denom = 1.0
+        for i in range(nth + 1):
+            if a == 0:
+                if i > 0:
+                    denom *= (2 * i) * (2 * i + 1)
+            else:
+                denom *= (2 * i + a) * (2 * i + a + 1)
+            ans = ans + (-1) ** i * theta ** (2 * i) / denom
+        return ans
+
+    def se3_to_SE3(self, wu):
+        w, u = wu[..., :3], wu[..., 3:]
+        O = torch.zeros_like(w[..., 0])
+        wx = torch.stack([torch.stack([O, -w[..., 2], w[..., 1]], -1),
+                          torch.stack([w[..., 2], O, -w[..., 0]], -1),
+                          torch.stack([-w[..., 1], w[..., 0], O], -1)], -2)
+        theta = w.norm(dim=-1)[..., None, None]
+        I = torch.eye(3, device=wu.device)
+        A, B, Cc = self._series(theta, 1.0), self._series(theta, 2.0), self._series(theta, 6.0)
+        R = I + A * wx + B * wx @ wx
+        V = I + B * wx + Cc * wx @ wx
+        return torch.cat([R, V @ u[..., None]], dim=-1)
+
+    # ------------------------------------------------------------------ reprojection branch (:147-152, 236-267)
+    def get_reproject_pixels(self, tag_wpts, intr_adj, pose_adj):
+        """Projects calibration points [B,C,P,3] through [R|t] and K -> pixel coords [B,C,P,2]."""
+        ones = torch.ones_like(tag_wpts[..., :1])
+        wh = torch.cat([tag_wpts, ones], dim=-1)                       # [B,C,P,4]
+        cam = wh @ pose_adj.unsqueeze(0).transpose(-2, -1)             # [B,C,P,3]
+        pix = cam @ intr_adj.unsqueeze(0).transpose(-2, -1)
+        return pix[..., :2] / pix[..., 2:]
+
+    # ------------------------------------------------------------------ reporting hooks used by main.py
+    def show_estimate_param(self, intr_show, pose_show, epoch, epoch_type):
+        intr_err = (intr_show[0] - intr_show[1]).abs()
+        pose_err = (pose_show[0] - pose_show[1]).abs()
+        logging.info("EPOCH {} |K err| fx {:.4f} fy {:.4f} ux {:.4f} uy {:.4f} | R {:.5f} T {:.5f}".format(
+            epoch, float(intr_err[:, 0, 0].mean()), float(intr_err[:, 1, 1].mean()), float(intr_err[:, 0, 2].mean()),
+            float(intr_err[:, 1, 2].mean()), float(pose_err[..., :3].mean()), float(pose_err[..., 3].mean())))
+
+    def show_RT_est_results(self, epoch, mode="train"):
+        logging.info("EPOCH {}: camera frusta plot skipped (visualisation is out of scope)".format(epoch))

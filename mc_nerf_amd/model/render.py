@@ -1,0 +1,190 @@
+"""Autograd glue between the reference-shaped Python API and the HIP kernels.
+
+``RenderTrainFn`` is one differentiable op for the whole of NeRF_Model.render_rays_train
+(reference: model/mc_nerf.py:598-646): coarse MLP -> composite -> device-side selection -> fine MLP ->
+composite, with a hand-written backward (composite bwd -> dX chain -> dW) instead of autograd
+through ~900 ATen ops.  ``RaygenFn`` does the same for MC_Model.get_rays on selected pixels.
+
+Every random draw of the reference (jitter, the three N(0,1) tensors of sigma2weights, the cap
+permutation) is an explicit tensor argument: generated with torch's device RNG by the caller in
+normal operation, passed in verbatim by the parity tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .. import ops
+
+
+@dataclass
+class RenderSettings:
+    """The renderer constants the kernels need (reference: model/mc_nerf.py:548-571)."""
+    samples_c: int
+    scale: int
+    weight_thresh: float
+    sigma_default: float
+    white_back: bool
+    max_fine_per_ray: int = 128      # model/mc_nerf.py:630
+
+    @property
+    def samples_f(self):
+        return self.samples_c * self.scale
+
+
+def _cap_needed(st: RenderSettings) -> bool:
+    """The cap of model/mc_nerf.py:630-632 can only bind when a ray can select more than 128 samples."""
+    return st.samples_f > st.max_fine_per_ray
+
+
+def select_and_cap(st: RenderSettings, w_sel, wmax, n_rays, cap_perm, train: bool):
+    """Device-side selection; applies the random cap in training.  Returns idx, count, out_f, max_rows."""
+    idx, count, out_f = ops.select_fine(w_sel, wmax, st.weight_thresh, st.scale, st.sigma_default)
+    max_rows = n_rays * st.samples_f
+    if train and _cap_needed(st):
+        keep = n_rays * st.max_fine_per_ray
+        k = int(count.item())                      # the only host sync of the train path; cfg 2 never takes it
+        if k > keep:
+            if cap_perm is None:
+                cap_perm = torch.randperm(k)[:keep]        # CPU generator, as the reference (:631)
+            perm = cap_perm[:keep].to(device=idx.device, dtype=torch.int64).contiguous()
+            idx, count = ops.cap_gather(idx, perm, keep)
+        max_rows = min(max_rows, max(k, 1)) if k <= keep else keep
+    return idx, count, out_f, max_rows
+
+
+class RenderTrainFn(torch.autograd.Function):
+    """rgb_c, rgb_f, depth_c = f(rays_d, rays_o, *coarse_params, *fine_params) with explicit draws."""
+
+    @staticmethod
+    def forward(ctx, owner, model_c, model_f, step_r, only_coarse, jitter, eps_c, eps_sel, eps_f, cap_perm,
+                rays_d, rays_o, *params):
+        st: RenderSettings = owner.settings
+        dev = rays_d.device
+        N = rays_d.shape[0]
+        rays_d = rays_d.contiguous()
+        rays_o = rays_o.contiguous()
+        need_grad = any(ctx.needs_input_grad)
+        barf_w = owner.emmbedding_xyz.barf_weights(step_r).to(dev)
+        jit = jitter.reshape(-1).contiguous()
+
+        # ---- coarse pass (dense [N,Sc] grid)
+        net_c = model_c.net
+        flat_c = model_c.flat_params()
+        packed_c = ops.pack_weights(net_c, flat_c)
+        out_c = torch.empty(N, st.samples_c, 4, dtype=torch.float32, device=dev)
+        save_c = ops.alloc_save(net_c, N * st.samples_c, dev) if need_grad else None
+        ops.mlp_fwd(net_c, flat_c, packed_c, rays_o, rays_d, owner.z_vals_c, jit, barf_w, out_c, save=save_c)
+        rgb_c, depth_c, _, w_sel, wmax = ops.composite_fwd(out_c, rays_d, owner.z_vals_c, jit, eps_c,
+                                                          None if only_coarse else eps_sel, st.white_back,
+                                                          want_depth=only_coarse)
+        ctx.only_coarse = only_coarse
+        ctx.owner, ctx.model_c, ctx.model_f = owner, model_c, model_f
+        ctx.n_c = len(model_c.ordered_parameters())
+        if only_coarse:
+            if need_grad:
+                ctx.save_for_backward(rays_d, rays_o, jit, eps_c, barf_w, out_c, flat_c, packed_c)
+                ctx.save_c = save_c
+            ctx.mark_non_differentiable(depth_c)
+            return rgb_c, None, depth_c
+
+        # ---- selection (no host sync) and fine pass on the compacted (ray, sample) list
+        idx, count, out_f, max_rows = select_and_cap(st, w_sel, wmax, N, cap_perm, train=True)
+        net_f = model_f.net
+        flat_f = model_f.flat_params()
+        packed_f = ops.pack_weights(net_f, flat_f)
+        save_f = ops.alloc_save(net_f, max_rows, dev) if need_grad else None
+        ops.mlp_fwd(net_f, flat_f, packed_f, rays_o, rays_d, owner.z_vals_f, jit, barf_w, out_f,
+                    idx=idx, count=count, max_rows=max_rows, save=save_f)
+        rgb_f, _, _, _, _ = ops.composite_fwd(out_f, rays_d, owner.z_vals_f, jit, eps_f, None, st.white_back)
+        if need_grad:
+            ctx.save_for_backward(rays_d, rays_o, jit, eps_c, barf_w, out_c, flat_c, packed_c,
+                                  eps_f, out_f, flat_f, packed_f, idx, count)
+            ctx.save_c, ctx.save_f, ctx.max_rows = save_c, save_f, max_rows
+        owner.last_selection = (idx, count)
+        return rgb_c, rgb_f, None
+
+    @staticmethod
+    def backward(ctx, d_rgb_c, d_rgb_f, _d_depth):
+        owner, model_c, model_f = ctx.owner, ctx.model_c, ctx.model_f
+        st: RenderSettings = owner.settings
+        saved = ctx.saved_tensors
+        rays_d, rays_o, jit, eps_c, barf_w, out_c, flat_c, packed_c = saved[:8]
+        dev = rays_d.device
+        N = rays_d.shape[0]
+        want_rays = ctx.needs_input_grad[10] or ctx.needs_input_grad[11]
+        d_o = torch.zeros(N, 3, dtype=torch.float32, device=dev) if want_rays else None
+        d_d = torch.zeros(N, 3, dtype=torch.float32, device=dev) if want_rays else None
+        g_c = torch.zeros_like(flat_c)
+        g_f = None
+
+        def net_backward(model, flat, packed, zgrid, eps, out, d_rgb, save, grads, idx=None, count=None, max_rows=0):
+            if d_rgb is None:
+                return
+            net = model.net
+            d_out = ops.composite_bwd(out, zgrid, jit, eps, d_rgb.contiguous(), st.white_back)
+            dy = torch.empty_like(save.act)
+            dsh = torch.empty_like(save.sh)
+            ops.mlp_bwd(net, flat, packed, rays_o, rays_d, zgrid, jit, barf_w, out, d_out, save, grads, dy, dsh,
+                        d_o, d_d, idx=idx, count=count, max_rows=max_rows)
+            rows = max_rows if idx is not None else N * zgrid.numel()
+            ops.mlp_dw(net, save, dy, dsh, grads, rows, count=count)
+
+        if not ctx.only_coarse:
+            eps_f, out_f, flat_f, packed_f, idx, count = saved[8:]
+            g_f = torch.zeros_like(flat_f)
+            net_backward(model_f, flat_f, packed_f, owner.z_vals_f, eps_f, out_f, d_rgb_f, ctx.save_f, g_f,
+                         idx=idx, count=count, max_rows=ctx.max_rows)
+            ctx.save_f = None
+        net_backward(model_c, flat_c, packed_c, owner.z_vals_c, eps_c, out_c, d_rgb_c, ctx.save_c, g_c)
+        ctx.save_c = None
+        grads_c = model_c.grad_views(g_c)
+        grads_f = model_f.grad_views(g_f) if g_f is not None else [None] * len(model_f.ordered_parameters())
+        owner.last_flat_grads = (g_c, g_f)
+        return (None,) * 10 + (d_d if ctx.needs_input_grad[10] else None,
+                               d_o if ctx.needs_input_grad[11] else None) + tuple(grads_c) + tuple(grads_f)
+
+
+def render_test(owner, model_c, model_f, rays_d, rays_o, eps_c, eps_sel, eps_f):
+    """NeRF_Model.render_rays_test (model/mc_nerf.py:648-680): no jitter, step_r = 1, no cap, no grad."""
+    st: RenderSettings = owner.settings
+    dev = rays_d.device
+    N = rays_d.shape[0]
+    rays_d = rays_d.contiguous()
+    rays_o = rays_o.contiguous()
+    barf_w = owner.emmbedding_xyz.barf_weights(1).to(dev)
+    net_c, net_f = model_c.net, model_f.net
+    flat_c, flat_f = model_c.flat_params(), model_f.flat_params()
+    packed_c, packed_f = ops.pack_weights(net_c, flat_c), ops.pack_weights(net_f, flat_f)
+    out_c = torch.empty(N, st.samples_c, 4, dtype=torch.float32, device=dev)
+    ops.mlp_fwd(net_c, flat_c, packed_c, rays_o, rays_d, owner.z_vals_c, None, barf_w, out_c)
+    _, _, _, w_sel, wmax = ops.composite_fwd(out_c, rays_d, owner.z_vals_c, None, eps_c, eps_sel, st.white_back)
+    idx, count, out_f, max_rows = select_and_cap(st, w_sel, wmax, N, None, train=False)
+    ops.mlp_fwd(net_f, flat_f, packed_f, rays_o, rays_d, owner.z_vals_f, None, barf_w, out_f,
+                idx=idx, count=count, max_rows=max_rows)
+    rgb, depth, opacity, _, _ = ops.composite_fwd(out_f, rays_d, owner.z_vals_f, None, eps_f, None, st.white_back,
+                                                  want_depth=True)
+    owner.last_selection = (idx, count)
+    return rgb, depth, opacity
+
+
+class RaygenFn(torch.autograd.Function):
+    """rays_d, rays_o = f(pose[3,4], kinv[3,3]) for the given pixel ids of one camera."""
+
+    @staticmethod
+    def forward(ctx, pose, kinv, pix, W):
+        pose = pose.contiguous().float()
+        kinv = kinv.contiguous().float()
+        pix = pix.contiguous()
+        d, o = ops.raygen_fwd(pose, kinv, pix, W)
+        ctx.save_for_backward(pose, kinv, pix)
+        ctx.W = W
+        return d, o
+
+    @staticmethod
+    def backward(ctx, g_d, g_o):
+        pose, kinv, pix = ctx.saved_tensors
+        d_pose, d_kinv = ops.raygen_bwd(pose, kinv, pix, ctx.W, g_d.contiguous(), g_o.contiguous())
+        return d_pose, d_kinv, None, None

@@ -53,3 +53,19 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def make_sys_param(cfg, device="cpu", mode=0, batch=128, **extra):
+    """The flat `sys_param` dict the reference builds from config.yaml (config/config_read.py:42-74),
+    restricted to the keys the hot path reads."""
+    p = dict(mode=mode, device_type=device, near=cfg.near, far=cfg.far, samples=cfg.samples, scale=cfg.scale,
+             MLP_deg=cfg.deg, white_back=cfg.white_back, root_weight="/tmp/mcnerf_w", demo_render_pth="/tmp/mcnerf_r",
+             batch=batch, boader_min=-3.5, boader_max=3.5, grid_nerf=384, sigma_init=30.0,
+             sigma_default=cfg.sigma_default, warmup_epoch=100, sample_weight_thresh=cfg.weight_thresh,
+             res_h=800, res_w=800, data_name="lego", emb_freqs_xyz=cfg.n_freqs, barf_mask=cfg.barf_mode,
+             barf_start=cfg.barf_start, barf_end=cfg.barf_end, coarse_MLP_depth=cfg.coarse.depth,
+             coarse_MLP_width=cfg.coarse.width, coarse_MLP_skip=list(cfg.coarse.skips),
+             fine_MLP_depth=cfg.fine.depth, fine_MLP_width=cfg.fine.width, fine_MLP_skip=list(cfg.fine.skips),
+             distributed=False)
+    p.update(extra)
+    return p
