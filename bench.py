@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train rays/sec of the MC-NeRF hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R]
+
+Workload = BASELINE.json configs[1]: Ball_Lego-shaped rig (110 cameras, 800x800), coarse 4x128 (64 samples)
++ fine 8x256 (128-sample grid), joint intrinsic/extrinsic optimisation stage (GLOBAL_OPTIM_EPOCH), synthetic
+images and random-init weights (no dataset / network here).  One step = one full pass of the hot path over a
+batch of R rays of one camera per rank: camera parametrisation -> ray generation -> coarse MLP -> composite ->
+selection -> fine MLP -> composite -> loss -> backward (composite, dX chain, dW, ray-gen) -> ONE gradient
+all-reduce (N > 1) -> RAdam step.  Inputs are resident in HBM before the timed region.
+
+For N > 1 launch as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs per evaluated sample, forward: 2 x weight MACs
+F_FINE, F_COARSE = 2 * 629248, 2 * 101632
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+class KernelTimer:
+    """HIP-event timing of selected C-ABI calls on the stream they are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = {}
+        self.enabled = False
+
+    def install(self):
+        from mc_nerf_amd import _lib
+        orig = _lib.call
+        timer = self
+
+        def timed(name, *args):
+            if not timer.enabled or name not in ("mcnerf_mlp_fwd", "mcnerf_mlp_bwd", "mcnerf_mlp_dw"):
+                return orig(name, *args)
+            key = (name, args[1])           # (entry point, net width)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = orig(name, *args)
+            b.record()
+            timer.records.setdefault(key, []).append((a, b))
+            return r
+
+        _lib.call = timed
+        from mc_nerf_amd import ops
+        ops._lib.call = timed
+
+    def summary(self):
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.records.items()}
+
+
+def cpu_baseline(n_rays=1536):
+    """The oracle (a plain-PyTorch CPU port of the reference path, parity-pinned in tests/) timed on the host
+    cores on a bounded sample of the same workload: train forward+backward of cfg-2 nets on n_rays rays."""
+    from oracle import mcnerf_oracle as O
+    torch.manual_seed(0)
+    cfg = O.RenderCfg(samples=64, scale=2)
+    pc = {k: v.requires_grad_(True) for k, v in O.init_params(cfg.coarse, 1).items()}
+    pf = {k: v.requires_grad_(True) for k, v in O.init_params(cfg.fine, 2).items()}
+
+    def run(n):
+        g = torch.Generator().manual_seed(n)
+        o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * 3.0
+        d = torch.nn.functional.normalize(-o + 0.5 * torch.randn(n, 3, generator=g), dim=-1)
+        jit = torch.rand(n, 1, generator=g) * 7.0 / 64
+        e = [torch.randn(n, s, generator=g) for s in (64, 64, 128)]
+        t0 = time.perf_counter()
+        r = O.render_rays_train(pc, pf, cfg, d, o, 1.0, jit, e[0], e[1], e[2])
+        O.rgb_loss(r["rgb_c"], r["rgb_f"], torch.rand(n, 3, generator=g)).backward()
+        return time.perf_counter() - t0, r["idx_f"].shape[0]
+
+    run(128)
+    dt, k = run(n_rays)
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle train fwd+bwd, cfg-2 nets, {n_rays} rays, {k} fine samples, 1 timed run after warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=32768, help="rays per step per GPU (config `batch`)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from mc_nerf_amd import distributed as D
+    rank, world, dev = D.init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd.model import MC_Model, MC_NeRF_Loss, RAdam
+
+    torch.manual_seed(42 + rank)                   # main.py:274-277: seed + rank
+    H = W = 800
+    sp = S.make_sys_param(dev, samples=64, scale=2, batch=args.rays, H=H, W=W, barf_mask=False)
+    model = MC_Model(sp).to(dev)
+    S.init_cameras_near_gt(model, noise=1e-3)
+    loss_fn = MC_NeRF_Loss(sp)
+    opt = RAdam(model.parameters(), lr=5e-4, weight_decay=4e-4)
+    sync = D.FlatGradSync(model, world)
+    sync.broadcast_parameters()
+    C = model.train_numb
+    wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0])
+    wpts, pts = wpts.to(dev), pts.to(dev)
+    imgs = torch.rand(4, H * W, 3, device=dev)      # synthetic GT images (throughput does not depend on them)
+    cams = D.shard_cameras(C, 0, rank, world, seed=42)
+    timer = KernelTimer()
+    timer.install()
+    counts = []
+
+    def step(i):
+        cam = cams[i % len(cams)]
+        data = (imgs[cam % 4].unsqueeze(0), torch.tensor([cam]), wpts, pts, wpts, pts)
+        loss_dict, _, _, _ = model(data, 20, "GLOBAL_OPTIM_EPOCH", 0.6)
+        loss = loss_fn(loss_dict, "GLOBAL_OPTIM_EPOCH")
+        opt.zero_grad(set_to_none=True)
+        sync.prepare()
+        loss.backward()
+        sync.sync()
+        opt.step()
+        if timer.enabled:
+            counts.append(model.nerf.last_selection[1].clone())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        k_mean = float(torch.stack(counts).float().mean())
+        ks = timer.summary()
+        # dominant kernel = the fused fine-net forward/backward/dW; report the slowest of the three against the
+        # exact-fp32 MFMA peak, using algorithmic FLOPs (2 x MACs x evaluated samples) per launch
+        cand = {"mlp_fwd<256>": (ks.get(("mcnerf_mlp_fwd", 256)), F_FINE * k_mean),
+                "mlp_bwd<256>": (ks.get(("mcnerf_mlp_bwd", 256)), F_FINE * k_mean),
+                "mlp_dw<256>": (ks.get(("mcnerf_mlp_dw", 256)), F_FINE * k_mean)}
+        kern_ms = {k: v[0] for k, v in cand.items() if v[0]}
+        dom = max(kern_ms, key=kern_ms.get)
+        ach = cand[dom][1] / (cand[dom][0] * 1e-3) / 1e12
+        total_rays = args.rays * world * args.steps
+        out = {
+            "metric": "train rays/sec (coarse+fine, 64+128 samples)", "value": total_rays / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Ball_Lego-shaped 110-view 800x800, coarse 4x128 @64 + fine 8x256 @128-grid, "
+                                   "GLOBAL_OPTIM stage, fwd+bwd+allreduce+RAdam",
+                       "rays_per_step_per_gpu": args.rays, "fine_samples_per_ray": k_mean / args.rays,
+                       "parallelism": f"dp{world} (cameras sharded, 1 flat all-reduce/step)"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel_ms": kern_ms,
+                         "step_algorithmic_tflops": 3 * (F_FINE * k_mean + F_COARSE * args.rays * 64) / 1e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

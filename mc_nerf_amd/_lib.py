@@ -7,6 +7,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
 
+# torch ships its own HIP runtime (torch/lib/libamdhip64.so).  It MUST be in the process before
+# libmcnerf.so is loaded, so that the library's libamdhip64 dependency resolves to the same runtime
+# instance that owns torch's streams and allocations (two runtimes in one process do not share devices).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmcnerf.so")
 ABI_VERSION = 1

@@ -1,0 +1,113 @@
+"""Data parallelism of the reference (DDP + DistributedSampler, main.py:60-62, data/data_read.py:358-360,
+utils/distributed_init.py:11-34) re-designed for one MI355X node: one process per GPU, cameras sharded over
+ranks, and ONE all-reduce per step over ONE flat fp32 gradient buffer (coarse net | fine net | camera
+parameters, <= 2.94 MB) instead of per-tensor buckets - the message is latency-bound on xGMI, so fewer,
+contiguous collectives are what matters.  `backend="nccl"` is RCCL on ROCm; the CPU tests
+run the same code over gloo.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None):
+    """env:// rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*), as utils/distributed_init.py:12-31.
+    Returns (rank, world, device)."""
+    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
+        if dev.type == "cuda":
+            torch.cuda.set_device(dev)
+        return 0, 1, dev
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    use_cuda = torch.cuda.is_available()
+    if backend is None:
+        backend = "nccl" if use_cuda else "gloo"
+    dev = torch.device("cuda", local) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(dev)
+    if not dist.is_initialized():
+        kw = {"device_id": dev} if (use_cuda and backend == "nccl") else {}
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kw)
+    return rank, world, dev
+
+
+def shard_cameras(num_cams: int, epoch: int, rank: int, world: int, seed: int = 0, shuffle: bool = True) -> List[int]:
+    """Camera ids this rank renders in `epoch`: a seeded permutation dealt round-robin, padded so every rank
+    takes the same number of steps (the semantics of DistributedSampler(shuffle=True) + set_epoch)."""
+    if shuffle:
+        g = torch.Generator().manual_seed(seed + epoch)
+        order = torch.randperm(num_cams, generator=g).tolist()
+    else:
+        order = list(range(num_cams))
+    total = ((num_cams + world - 1) // world) * world
+    order = order + order[: total - num_cams]
+    return order[rank:total:world]
+
+
+class FlatGradSync:
+    """One-collective gradient averaging for MC_Model.
+
+    Before `loss.backward()` call `prepare()`: it hands the renderer a zeroed arena so that the HIP backward
+    accumulates the two nets' gradients directly into one contiguous buffer.  After backward call `sync()`:
+    camera-parameter gradients are appended, the arena is all-reduced once (SUM, then divided by the world
+    size = DDP's averaging) and the parameters' `.grad` are pointed at / refreshed from it.
+    """
+
+    def __init__(self, model, world: int):
+        self.model, self.world = model, world
+        nerf = model.nerf
+        self.nets = [nerf.nerf_coarse, nerf.nerf_fine]
+        for n in self.nets:
+            n.flat_params()
+        self.net_sizes = [n.flat_params().numel() for n in self.nets]
+        self.cam_params = [p for name, p in model.named_parameters() if not name.startswith("nerf.")]
+        self.cam_sizes = [p.numel() for p in self.cam_params]
+        self.total = sum(self.net_sizes) + sum(self.cam_sizes)
+        dev = self.nets[0].flat_params().device
+        self.arena = torch.zeros(self.total, dtype=torch.float32, device=dev)
+
+    def broadcast_parameters(self):
+        """Rank 0's parameters to everyone (what the DDP constructor does, main.py:61)."""
+        if self.world <= 1:
+            return
+        for n in self.nets:
+            dist.broadcast(n.flat_params(), src=0)
+        for p in self.cam_params:
+            dist.broadcast(p.data, src=0)
+
+    def prepare(self):
+        self.arena.zero_()
+        self.model.nerf.grad_arena = self.arena
+
+    def sync(self):
+        """Call once after the step's single backward()."""
+        nerf = self.model.nerf
+        used = getattr(nerf, "grad_arena_used", False)
+        pairs = []
+        o = 0
+        for n, sz in zip(self.nets, self.net_sizes):
+            for p, po in zip(n.ordered_parameters(), n._offsets):
+                v = self.arena[o + po:o + po + p.numel()].view(p.shape)
+                if p.grad is not None and not used:      # backward ran without the arena: gather
+                    v.copy_(p.grad)
+                pairs.append((p, v))
+            o += sz
+        for p, sz in zip(self.cam_params, self.cam_sizes):
+            v = self.arena[o:o + sz].view(p.shape)
+            if p.grad is not None:
+                v.copy_(p.grad)
+            pairs.append((p, v))
+            o += sz
+        if self.world > 1:
+            dist.all_reduce(self.arena, op=dist.ReduceOp.SUM)     # the step's ONE collective
+            self.arena.div_(self.world)
+        for p, v in pairs:
+            if p.grad is not None:
+                p.grad = v
+        nerf.grad_arena = None
+        nerf.grad_arena_used = False

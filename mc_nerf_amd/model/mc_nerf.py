@@ -66,6 +66,8 @@ class NeRF_Model(nn.Module):
                                        float(self.sigma_default), bool(self.white_back))
         self.last_selection = None
         self.last_flat_grads = None
+        self.grad_arena = None            # set per step by distributed.FlatGradSync.prepare()
+        self.grad_arena_used = False
         if self.mode != 0:
             self.nerf_ckpt_name = sys_param["demo_ckpt"]
             ckpt = torch.load(Path(self.nerf_ckpt_name), map_location=self.device)

@@ -117,7 +117,15 @@ class RenderTrainFn(torch.autograd.Function):
         want_rays = ctx.needs_input_grad[10] or ctx.needs_input_grad[11]
         d_o = torch.zeros(N, 3, dtype=torch.float32, device=dev) if want_rays else None
         d_d = torch.zeros(N, 3, dtype=torch.float32, device=dev) if want_rays else None
-        g_c = torch.zeros_like(flat_c)
+        # gradient buffers: slices of the step-level arena when a FlatGradSync provided one (so the whole
+        # step's gradient is one contiguous all-reduce message), otherwise fresh zeroed buffers
+        arena = getattr(owner, "grad_arena", None)
+        n_c, n_f = flat_c.numel(), model_f.flat_params().numel()
+        if arena is not None:
+            g_c = arena[:n_c]
+            owner.grad_arena_used = True
+        else:
+            g_c = torch.zeros_like(flat_c)
         g_f = None
 
         def net_backward(model, flat, packed, zgrid, eps, out, d_rgb, save, grads, idx=None, count=None, max_rows=0):
@@ -134,7 +142,7 @@ class RenderTrainFn(torch.autograd.Function):
 
         if not ctx.only_coarse:
             eps_f, out_f, flat_f, packed_f, idx, count = saved[8:]
-            g_f = torch.zeros_like(flat_f)
+            g_f = arena[n_c:n_c + n_f] if arena is not None else torch.zeros_like(flat_f)
             net_backward(model_f, flat_f, packed_f, owner.z_vals_f, eps_f, out_f, d_rgb_f, ctx.save_f, g_f,
                          idx=idx, count=count, max_rows=ctx.max_rows)
             ctx.save_f = None
