@@ -82,13 +82,15 @@ static inline McnLayout mcn_make_layout(int depth, int width, int skip) {
     return L;
 }
 
-// Tile geometry per width: 8 waves = WN (along outputs) x WM (along samples);
-// each wave owns NI x MI MFMA tiles of 32x32.
+// Tile geometry per width: a workgroup is WN (along outputs) x WM (along samples) waves; each wave owns
+// NI x MI MFMA tiles of 32x32.  Tiles are 64 samples (4 waves) for the production widths so that TWO
+// workgroups are resident per CU (LDS ~77 KB each at width 256): while one is in a layer epilogue
+// (bias/ReLU/LDS write/activation save, barriers) the other keeps the MFMA pipe busy.
 template <int WIDTH> struct McnGeom;
-template <> struct McnGeom<256> { static constexpr int WN = 4, NI = 2, WM = 2, MI = 2; };
-template <> struct McnGeom<128> { static constexpr int WN = 4, NI = 1, WM = 2, MI = 2; };
-template <> struct McnGeom<64>  { static constexpr int WN = 2, NI = 1, WM = 4, MI = 1; };
-template <> struct McnGeom<32>  { static constexpr int WN = 1, NI = 1, WM = 8, MI = 1; };
+template <> struct McnGeom<256> { static constexpr int WN = 4, NI = 2, WM = 1, MI = 2; };
+template <> struct McnGeom<128> { static constexpr int WN = 4, NI = 1, WM = 1, MI = 2; };
+template <> struct McnGeom<64>  { static constexpr int WN = 2, NI = 1, WM = 2, MI = 1; };
+template <> struct McnGeom<32>  { static constexpr int WN = 1, NI = 1, WM = 4, MI = 1; };
 
 #ifdef __HIPCC__
 // Swizzled float offset of element (row m, column k) in an LDS tile with XW floats per row.
@@ -108,22 +110,33 @@ template <int NI, int MI>
 __device__ __forceinline__ void mcn_gemm_seg(f32x16 (&acc)[NI][MI], const float* X, int xw, int mrow0,
                                              int kchunk0, int KS, const f32x4* __restrict__ P, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    f32x4 a_n[NI];
+    // software pipeline: weight fragments two k-steps ahead (L2 latency), activation fragments one ahead (LDS)
+    f32x4 a0[NI], a1[NI], b_n[MI];
+    int xoff[MI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) a_n[ni] = P[(ni * KS) * 64 + lane];
+    for (int mi = 0; mi < MI; ++mi) xoff[mi] = (mrow0 + mi * 32 + r) * xw;
+    const int sw = (mrow0 + r) & 15;            // rows of all mi tiles share (row & 15): tiles are 32 rows apart
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        a0[ni] = P[(ni * KS) * 64 + lane];
+        a1[ni] = P[(ni * KS + (KS > 1 ? 1 : 0)) * 64 + lane];
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) b_n[mi] = *reinterpret_cast<const f32x4*>(&X[xoff[mi] + (((kchunk0 + h) ^ sw) << 2)]);
     for (int ks = 0; ks < KS; ++ks) {
-        f32x4 a_c[NI];
+        f32x4 a_c[NI], b[MI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) a_c[ni] = a_n[ni];
+        for (int ni = 0; ni < NI; ++ni) { a_c[ni] = a0[ni]; a0[ni] = a1[ni]; }
+        if (ks + 2 < KS) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) a1[ni] = P[(ni * KS + ks + 2) * 64 + lane];
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) b[mi] = b_n[mi];
         if (ks + 1 < KS) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) a_n[ni] = P[(ni * KS + ks + 1) * 64 + lane];
-        }
-        f32x4 b[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int m = mrow0 + mi * 32 + r;
-            b[mi] = *reinterpret_cast<const f32x4*>(&X[mcn_swz_chunk(m, kchunk0 + 2 * ks + h, xw)]);
+            for (int mi = 0; mi < MI; ++mi)
+                b_n[mi] = *reinterpret_cast<const f32x4*>(&X[xoff[mi] + (((kchunk0 + 2 * (ks + 1) + h) ^ sw) << 2)]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)

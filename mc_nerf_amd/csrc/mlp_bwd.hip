@@ -15,12 +15,14 @@ template <int WIDTH>
 struct BwdSmem {
     using G = McnGeom<WIDTH>;
     static constexpr int MT = G::WM * G::MI * 32;
+    static constexpr int NT = G::WN * G::WM * 64;
     static constexpr int XW = WIDTH > 64 ? WIDTH : 64;
     static constexpr int oX = 0;
     static constexpr int oDsig = oX + MT * XW;        // [MT] d sigma_raw
     static constexpr int oDdir = oDsig + MT;          // [MT][4] d view-direction from the SH colour
-    static constexpr int oRed = oDdir + MT * 4;       // [512] reduction scratch
-    static constexpr int oAddr = oRed + 512;          // [MT] int ray id (or -1)
+    static constexpr int oGo = oDdir + MT * 4;        // [MT][4] d sample position (= d ray origin contribution)
+    static constexpr int oRed = oGo + MT * 4;         // [16] reduction scratch
+    static constexpr int oAddr = oRed + 16;           // [MT] int ray id (or -1)
     static constexpr int oZ = oAddr + MT;             // [MT] z value
     static constexpr int total = oZ + MT;
     static constexpr size_t bytes = (size_t)total * 4;
@@ -52,16 +54,17 @@ __device__ __forceinline__ void mask_store(f32x16 (&acc)[NI][MI], const float* _
 }
 
 template <int WIDTH>
-__global__ __launch_bounds__(512) void mlp_bwd_kernel(McnMlpBwdArgs a) {
+__global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) void mlp_bwd_kernel(McnMlpBwdArgs a) {
     using G = McnGeom<WIDTH>;
     using SM = BwdSmem<WIDTH>;
-    constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN;
+    constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN, NT = SM::NT, WAVES = NT / 64;
     constexpr int NSH = WIDTH / 8;            // reduction steps over a hidden-wide dY
     constexpr int W4 = WIDTH / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem + SM::oX;
     float* sdsig = smem + SM::oDsig;
     float* sddir = smem + SM::oDdir;
+    float* sgo = smem + SM::oGo;
     float* sred = smem + SM::oRed;
     int* sray = reinterpret_cast<int*>(smem + SM::oAddr);
     float* sz = smem + SM::oZ;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(McnMlpBwdArgs a) {
 
     // ---- per-sample prologue: sigmoid and SH backward -> dsh (the dY of sh.2), d sigma, d dir
     float bs2_part = 0.f;
-    for (int m = tid; m < MT; m += 512) {
+    for (int m = tid; m < MT; m += NT) {
         const long long g = row0 + m;
         __attribute__((aligned(16))) float dsh[MCN_NSHP];
 #pragma unroll
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(McnMlpBwdArgs a) {
         const float* hs = a.act_save + (size_t)D * AS;
         float* dys = a.dy_save + (size_t)D * AS;
         const float* w2 = prm + L.pWs2;
-        constexpr int MG = 512 / W4;            // sample groups (512 threads / chunks per row)
+        constexpr int MG = NT / W4;             // sample groups (threads / chunks per row)
         const int c4 = tid % W4, mg = tid / W4;
         const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + 4 * c4);
         f32x4 gw = {0.f, 0.f, 0.f, 0.f};
@@ -172,8 +175,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(McnMlpBwdArgs a) {
     f32x16 denc[1][1];
     mcn_zero<1, 1>(denc);
     constexpr int ENC_TILES = 2 * (MT / 32);          // (2 k-tiles of the 64 encoded channels) x m-tiles
-    static_assert(ENC_TILES <= 16, "at most two encoded-gradient tiles per wave");
-    f32x16 denc2[1][1];                                // second tile when ENC_TILES > 8 (MT = 256)
+    static_assert(ENC_TILES <= 2 * WAVES, "at most two encoded-gradient tiles per wave");
+    f32x16 denc2[1][1];                                // second tile when ENC_TILES > WAVES
     mcn_zero<1, 1>(denc2);
     for (int l = D - 1; l >= 0; --l) {
         if (l == 0 || l == L.skip) {
@@ -182,8 +185,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(McnMlpBwdArgs a) {
                 const int t = wave;
                 if (t < ENC_TILES) mcn_gemm_seg<1, 1>(denc, X, XW, (t >> 1) * 32, 0, NSH, pe + (t & 1) * NSH * 64, lane);
             }
-            if (ENC_TILES > 8) {
-                const int t = wave + 8;
+            if (ENC_TILES > WAVES) {
+                const int t = wave + WAVES;
                 if (t < ENC_TILES) mcn_gemm_seg<1, 1>(denc2, X, XW, (t >> 1) * 32, 0, NSH, pe + (t & 1) * NSH * 64, lane);
             }
         }
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(McnMlpBwdArgs a) {
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            const int t = wave + 8 * pass;
+            const int t = wave + WAVES * pass;
             if (t < ENC_TILES) {
                 const int mt = t >> 1, kt = t & 1;
 #pragma unroll
@@ -217,21 +220,39 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(McnMlpBwdArgs a) {
     // ---- encoding backward -> d xyz -> d rays_o / d rays_d
     //   enc channel 3+20c+f = w_f sin(2^f x_c), 3+20c+10+f = w_f cos(2^f x_c)  (w_f already inside enc_save)
     if (a.d_rays_o || a.d_rays_d) {
-        for (int it = tid; it < MT * 3; it += 512) {
+        for (int it = tid; it < MT * 3; it += NT) {
             const int m = it / 3, c = it - m * 3;
             const long long g = row0 + m;
-            if (g >= total) continue;
-            const float* en = a.enc_save + (size_t)g * MCN_ENCP;
-            float dx = X[mcn_swz(m, c, XW)];
+            float dx = 0.f;
+            if (g < total) {
+                const float* en = a.enc_save + (size_t)g * MCN_ENCP;
+                dx = X[mcn_swz(m, c, XW)];
 #pragma unroll
-            for (int f = 0; f < MCN_NFREQ; ++f) {
-                const float s = en[3 + 20 * c + f], co = en[3 + 20 * c + 10 + f];
-                const float ds = X[mcn_swz(m, 3 + 20 * c + f, XW)], dc = X[mcn_swz(m, 3 + 20 * c + 10 + f, XW)];
-                dx += (float)(1 << f) * (co * ds - s * dc);
+                for (int f = 0; f < MCN_NFREQ; ++f) {
+                    const float s = en[3 + 20 * c + f], co = en[3 + 20 * c + 10 + f];
+                    const float ds = X[mcn_swz(m, 3 + 20 * c + f, XW)], dc = X[mcn_swz(m, 3 + 20 * c + 10 + f, XW)];
+                    dx += (float)(1 << f) * (co * ds - s * dc);
+                }
             }
+            sgo[m * 4 + c] = dx;                                       // d origin
+            sddir[m * 4 + c] = dx * sz[m] + sddir[m * 4 + c];          // d direction: through x = o + d z, plus the SH term
+        }
+        __syncthreads();
+        // samples of one ray are contiguous in the tile: the first sample of each run sums the run, so a
+        // ray costs 6 atomics per tile instead of 6 per sample (64-way same-address contention otherwise)
+        for (int m = tid; m < MT; m += NT) {
             const int ray = sray[m];
-            if (a.d_rays_o) atomicAdd(a.d_rays_o + ray * 3 + c, dx);
-            if (a.d_rays_d) atomicAdd(a.d_rays_d + ray * 3 + c, dx * sz[m] + sddir[m * 4 + c]);
+            if (ray < 0 || (m > 0 && sray[m - 1] == ray)) continue;
+            float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+            for (int mm = m; mm < MT && sray[mm] == ray; ++mm) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { so[c] += sgo[mm * 4 + c]; sd[c] += sddir[mm * 4 + c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (a.d_rays_o) atomicAdd(a.d_rays_o + ray * 3 + c, so[c]);
+                if (a.d_rays_d) atomicAdd(a.d_rays_d + ray * 3 + c, sd[c]);
+            }
         }
     }
     // ---- d bias of sigma.2 = sum of d sigma over the tile
@@ -243,7 +264,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(McnMlpBwdArgs a) {
         __syncthreads();
         if (tid == 0) {
             float s = 0.f;
-            for (int w = 0; w < 8; ++w) s += sred[w];
+            for (int w = 0; w < WAVES; ++w) s += sred[w];
             atomicAdd(a.grads + L.pBs2, s);
         }
     }
@@ -257,7 +278,7 @@ static hipError_t launch_bwd(const McnMlpBwdArgs& a, long long max_rows, hipStre
     auto kern = mlp_bwd_kernel<WIDTH>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SM::bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SM::NT), SM::bytes, st, a);
     return hipGetLastError();
 }
 

@@ -50,32 +50,36 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
 
     const float* pa = s.dY + nbase + VN * r;
     const float* pb = s.X + kbase + r;
-    for (int m = r0 + 2 * ms; m < r1; m += 4 * MS) {
-        // two row pairs per iteration: loads of both in flight before the MFMAs
-        AV a0, a1;
-        float b0[KT], b1[KT];
-        const int row0 = m + h, row1 = m + 2 * MS + h;
-        const bool ok0 = row0 < r1, ok1 = row1 < r1;
-        if (ok0) a0 = *reinterpret_cast<const AV*>(pa + (size_t)row0 * s.ldy); else a0 = AV(0.f);
-        if (ok1) a1 = *reinterpret_cast<const AV*>(pa + (size_t)row1 * s.ldy); else a1 = AV(0.f);
+    // Register pipeline: PF row pairs in flight per wave (HBM latency ~2 us vs 8 MFMAs = 0.2 us per pair).
+    constexpr int PF = 8;
+    AV av[PF];
+    float bv[PF][KT];
+    const int stride = 2 * MS;
+    auto load = [&](AV& a_dst, float (&b_dst)[KT], int mrow) {
+        const int row = mrow + h;
+        const bool ok = row < r1;
+        if (ok) a_dst = *reinterpret_cast<const AV*>(pa + (size_t)row * s.ldy); else a_dst = AV(0.f);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            b0[kt] = ok0 ? pb[(size_t)row0 * s.ldx + 32 * kt] : 0.f;
-            b1[kt] = ok1 ? pb[(size_t)row1 * s.ldx + 32 * kt] : 0.f;
-        }
+        for (int kt = 0; kt < KT; ++kt) b_dst[kt] = ok ? pb[(size_t)row * s.ldx + 32 * kt] : 0.f;
+    };
+    int m = r0 + 2 * ms;
 #pragma unroll
-        for (int t = 0; t < VN; ++t) {
-            const float av = vget<VN>(a0, t);
-            bsum[t] += av;
+    for (int p = 0; p < PF; ++p) load(av[p], bv[p], m + p * stride);
+    for (; m < r1; m += PF * stride) {
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc[t][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[kt], acc[t][kt], 0, 0, 0);
-        }
+        for (int p = 0; p < PF; ++p) {
+            const AV a_c = av[p];
+            float b_c[KT];
 #pragma unroll
-        for (int t = 0; t < VN; ++t) {
-            const float av = vget<VN>(a1, t);
-            bsum[t] += av;
+            for (int kt = 0; kt < KT; ++kt) b_c[kt] = bv[p][kt];
+            load(av[p], bv[p], m + (p + PF) * stride);          // refill the slot for PF pairs later
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc[t][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1[kt], acc[t][kt], 0, 0, 0);
+            for (int t = 0; t < VN; ++t) {
+                const float a1 = vget<VN>(a_c, t);
+                bsum[t] += a1;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) acc[t][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b_c[kt], acc[t][kt], 0, 0, 0);
+            }
         }
     }
     // accumulators -> global (float atomics; one register = two 128-byte row segments)

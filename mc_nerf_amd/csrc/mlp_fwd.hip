@@ -16,6 +16,7 @@ template <int WIDTH>
 struct FwdSmem {
     using G = McnGeom<WIDTH>;
     static constexpr int MT = G::WM * G::MI * 32;
+    static constexpr int NT = G::WN * G::WM * 64;       // threads per workgroup
     static constexpr int XW = WIDTH > 64 ? WIDTH : 64;
     static constexpr int oX = 0;
     static constexpr int oXyz = oX + MT * XW;          // [MT][4]  x,y,z,z_val
@@ -49,10 +50,10 @@ __device__ __forceinline__ void write_encoding(float* X, const float* sxyz, cons
 }
 
 template <int WIDTH, bool SAVE>
-__global__ __launch_bounds__(512) void mlp_fwd_kernel(McnMlpFwdArgs a) {
+__global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) void mlp_fwd_kernel(McnMlpFwdArgs a) {
     using G = McnGeom<WIDTH>;
     using SM = FwdSmem<WIDTH>;
-    constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN;
+    constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN, NT = SM::NT, WAVES = NT / 64;
     constexpr int KSH = WIDTH / 8;      // k-steps of a hidden segment
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem + SM::oX;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(McnMlpFwdArgs a) {
     const f32x4* __restrict__ pk = reinterpret_cast<const f32x4*>(a.packed);
 
     // ---- per-sample setup: position, direction, output address
-    for (int m = tid; m < MT; m += 512) {
+    for (int m = tid; m < MT; m += NT) {
         const long long g = row0 + m;
         float x = 0.f, y = 0.f, z = 0.f, dx = 0.f, dy = 0.f, dz = 1.f, zv = 0.f;
         int addr = -1;
@@ -97,10 +98,10 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(McnMlpFwdArgs a) {
         saddr[m] = addr;
     }
     __syncthreads();
-    write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, 512);
+    write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT);
     __syncthreads();
     if (SAVE) {   // encoded inputs are the X operand of dW for layer 0 and the skip layer
-        for (int it = tid; it < MT * 16; it += 512) {
+        for (int it = tid; it < MT * 16; it += NT) {
             const int m = it >> 4, ch = it & 15;
             if (row0 + m < total)
                 *reinterpret_cast<f32x4*>(a.enc_save + (size_t)(row0 + m) * MCN_ENCP + ch * 4) =
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(McnMlpFwdArgs a) {
             mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, KSH, pk + (L.fH[l] >> 2) + (wn * NI) * KSH * 64, lane);
             if (l == L.skip) {
                 __syncthreads();                       // everyone finished reading h from X
-                write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, 512);
+                write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT);
                 __syncthreads();
                 mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_ENCP / 8, pk + (L.fEncS >> 2) + (wn * NI) * (MCN_ENCP / 8) * 64, lane);
             }
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(McnMlpFwdArgs a) {
         __syncthreads();
     }
     // ---- SH output layer (27 -> 32 padded outputs): one 32-row m-tile per wave
-    for (int mt = wave; mt < MT / 32; mt += 8) {
+    for (int mt = wave; mt < MT / 32; mt += WAVES) {
         f32x16 a1[1][1];
         mcn_zero<1, 1>(a1);
         mcn_gemm_seg<1, 1>(a1, X, XW, mt * 32, 0, KSH, pk + (L.fC2 >> 2), lane);
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(512) void mlp_fwd_kernel(McnMlpFwdArgs a) {
     }
     __syncthreads();
     // ---- per-sample epilogue: sigma, SH colour, sigmoid
-    for (int m = tid; m < MT; m += 512) {
+    for (int m = tid; m < MT; m += NT) {
         const long long g = row0 + m;
         if (g >= total) continue;
         float sigma = prm[L.pBs2];
@@ -259,7 +260,7 @@ static hipError_t launch_fwd(const McnMlpFwdArgs& a, long long max_rows, hipStre
     auto kern = save ? mlp_fwd_kernel<WIDTH, true> : mlp_fwd_kernel<WIDTH, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SM::bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SM::NT), SM::bytes, st, a);
     return hipGetLastError();
 }
 
