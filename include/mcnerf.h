@@ -66,28 +66,29 @@ int mcnerf_raygen_bwd(const float* pose, const float* kinv, const int64_t* pix, 
  *                 beyond *count exit, so no host sync is needed to size the launch;
  *   out  [n_rays,S,4] = (sigma_raw, r, g, b) written at (ray, sample); entries not listed in idx are
  *        left untouched (mcnerf_select_fine pre-fills the reference's defaults);
- *   act_save / enc_save / sh_save: NULL for the no-grad path; otherwise workspaces of
- *        (depth+2)*capacity*width, capacity*64 and capacity*32 floats that receive what
- *        mcnerf_mlp_bwd / mcnerf_mlp_dw need (capacity >= number of evaluated samples). */
+ *   act_save / enc_save / sh_save / mask_save: NULL for the no-grad path; otherwise workspaces of
+ *        (depth+2)*capacity*width, capacity*64, capacity*32 floats and (depth+2)*capacity*width/32
+ *        uint32 (1-bit ReLU masks) that receive what mcnerf_mlp_bwd / mcnerf_mlp_dw need
+ *        (capacity >= number of evaluated samples). */
 int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const float* packed,
                    const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
                    const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                    int n_rays, int S, float* out,
-                   float* act_save, long long capacity, float* enc_save, float* sh_save, void* stream);
+                   float* act_save, long long capacity, float* enc_save, float* sh_save, uint32_t* mask_save,
+                   void* stream);
 
 /* Backward of mcnerf_mlp_fwd wrt the activations (the dX chain): consumes d_out [n_rays,S,4],
  * writes the pre-activation gradients of every layer to dy_save ((depth+2)*capacity*width floats) and
- * dsh_save (capacity*32), ACCUMULATES d_rays_o / d_rays_d [n_rays,3] (through the sample positions,
- * the encoding and the SH view direction; either may be NULL) and ACCUMULATES the gradients of the
- * 1-wide sigma.2 layer into `grads` (flat parameter layout; the other weight gradients come from
- * mcnerf_mlp_dw).
+ * dsh_save (capacity*32: d sh.2 outputs in columns 0..26, d sigma_raw in column 27) and ACCUMULATES
+ * d_rays_o / d_rays_d [n_rays,3] (through the sample positions, the encoding and the SH view
+ * direction; either may be NULL).  All weight gradients come from mcnerf_mlp_dw.
  * Replaces autograd through model/net_block.py:22-33, 67-78 and model/mc_nerf.py:602, 635, 690-691. */
 int mcnerf_mlp_bwd(int depth, int width, int skip, const float* params, const float* packed,
                    const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
                    const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                    int n_rays, int S, const float* out, const float* d_out,
-                   const float* act_save, long long capacity, const float* enc_save, const float* sh_save,
-                   float* grads, float* dy_save, float* dsh_save, float* d_rays_o, float* d_rays_d, void* stream);
+                   const uint32_t* mask_save, long long capacity, const float* enc_save, const float* sh_save,
+                   float* dy_save, float* dsh_save, float* d_rays_o, float* d_rays_d, void* stream);
 
 /* Weight / bias gradients of one net: dW_l = dY_l^T X_l, db_l = sum_rows dY_l, ACCUMULATED into
  * `grads` (flat, same layout as the parameters; caller zeroes it once per step).

@@ -31,9 +31,9 @@ SIGNATURES = {
     "mcnerf_pack_weights": (_I, [_I, _I, _I, _P, _P, _P]),
     "mcnerf_raygen_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "mcnerf_raygen_bwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "mcnerf_mlp_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P]),
+    "mcnerf_mlp_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
     "mcnerf_mlp_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,
-                            _P, _P, _P, _P, _P, _P]),
+                            _P, _P, _P, _P, _P]),
     "mcnerf_mlp_dw": (_I, [_I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P]),
     "mcnerf_composite_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mcnerf_composite_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),

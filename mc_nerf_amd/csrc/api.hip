@@ -69,21 +69,21 @@ int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const fl
                    const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
                    const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                    int n_rays, int S, float* out,
-                   float* act_save, long long capacity, float* enc_save, float* sh_save, void* stream) {
+                   float* act_save, long long capacity, float* enc_save, float* sh_save, uint32_t* mask_save, void* stream) {
     REQ(net_ok(depth, width, skip), "mcnerf_mlp_fwd");
     REQ(params && packed && rays_o && rays_d && zgrid && barf_w && out && n_rays >= 0 && S > 0, "mcnerf_mlp_fwd");
     REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_fwd");
     REQ(!idx || max_rows >= 0, "mcnerf_mlp_fwd");
     REQ((long long)n_rays * S < (1ll << 31), "mcnerf_mlp_fwd");
     if (act_save) {
-        REQ(enc_save && sh_save, "mcnerf_mlp_fwd");
+        REQ(enc_save && sh_save && mask_save, "mcnerf_mlp_fwd");
         REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_fwd");
     }
     McnMlpFwdArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
     a.params = params; a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter;
     a.barf_w = barf_w; a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
-    a.out = out; a.act_save = act_save; a.act_stride = (size_t)capacity * width; a.enc_save = enc_save; a.sh_save = sh_save;
+    a.out = out; a.act_save = act_save; a.act_stride = (size_t)capacity * width; a.enc_save = enc_save; a.sh_save = sh_save; a.mask_save = mask_save;
     return check("mcnerf_mlp_fwd", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
 }
 
@@ -91,19 +91,19 @@ int mcnerf_mlp_bwd(int depth, int width, int skip, const float* params, const fl
                    const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
                    const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                    int n_rays, int S, const float* out, const float* d_out,
-                   const float* act_save, long long capacity, const float* enc_save, const float* sh_save,
-                   float* grads, float* dy_save, float* dsh_save, float* d_rays_o, float* d_rays_d, void* stream) {
+                   const uint32_t* mask_save, long long capacity, const float* enc_save, const float* sh_save,
+                   float* dy_save, float* dsh_save, float* d_rays_o, float* d_rays_d, void* stream) {
     REQ(net_ok(depth, width, skip), "mcnerf_mlp_bwd");
     REQ(params && packed && rays_o && rays_d && zgrid && barf_w && out && d_out && n_rays >= 0 && S > 0, "mcnerf_mlp_bwd");
-    REQ(act_save && enc_save && sh_save && dy_save && dsh_save, "mcnerf_mlp_bwd");
+    REQ(mask_save && enc_save && sh_save && dy_save && dsh_save, "mcnerf_mlp_bwd");
     REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_bwd");
     REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_bwd");
     McnMlpBwdArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
     a.params = params; a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter;
     a.barf_w = barf_w; a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
-    a.out = out; a.d_out = d_out; a.act_save = act_save; a.act_stride = (size_t)capacity * width;
-    a.enc_save = enc_save; a.sh_save = sh_save; a.grads = grads; a.dy_save = dy_save; a.dsh_save = dsh_save;
+    a.out = out; a.d_out = d_out; a.mask_save = mask_save; a.act_stride = (size_t)capacity * width;
+    a.enc_save = enc_save; a.sh_save = sh_save; a.dy_save = dy_save; a.dsh_save = dsh_save;
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d;
     return check("mcnerf_mlp_bwd", mcn_launch_mlp_bwd(a, (hipStream_t)stream));
 }

@@ -123,6 +123,7 @@ __device__ __forceinline__ void mcn_gemm_seg(f32x16 (&acc)[NI][MI], const float*
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) b_n[mi] = *reinterpret_cast<const f32x4*>(&X[xoff[mi] + (((kchunk0 + h) ^ sw) << 2)]);
+#pragma unroll 2
     for (int ks = 0; ks < KS; ++ks) {
         f32x4 a_c[NI], b[MI];
 #pragma unroll

@@ -20,6 +20,7 @@ struct McnMlpFwdArgs {
     size_t act_stride;        // floats between layers = capacity * width
     float* enc_save;          // [capacity][64]
     float* sh_save;           // [capacity][32]
+    unsigned int* mask_save;  // [(depth+2)][capacity][width/32] ReLU masks (bit c of word g = column 32g+c is > 0)
 };
 hipError_t mcn_launch_mlp_fwd(const McnMlpFwdArgs& a, hipStream_t st);
 int mcn_mlp_tile_rows(int width);
@@ -39,13 +40,12 @@ struct McnMlpBwdArgs {
     int n_rays, S;
     const float* out;         // forward output [n_rays,S,4]
     const float* d_out;       // upstream gradient [n_rays,S,4]
-    const float* act_save;    // forward activations
-    size_t act_stride;
+    const unsigned int* mask_save;   // ReLU masks written by the forward
+    size_t act_stride;        // capacity * width (stride between the layers of dy_save; masks use act_stride / 32)
     const float* enc_save;    // [capacity][64] encoded inputs (already BARF-weighted)
     const float* sh_save;
-    float* grads;             // flat gradient buffer: only d sigma.2.{weight,bias} are added here (may be null)
     float* dy_save;           // [(depth+2)][act_stride] pre-activation gradients (dW operands)
-    float* dsh_save;          // [capacity][32] gradient of the sh.2 outputs
+    float* dsh_save;          // [capacity][32] gradient of the sh.2 outputs (cols 0..26) and of sigma_raw (col 27)
     float* d_rays_o;          // [n_rays,3] accumulated with atomics (may be null)
     float* d_rays_d;          // [n_rays,3]
 };

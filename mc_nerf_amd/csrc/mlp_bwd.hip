@@ -21,18 +21,28 @@ struct BwdSmem {
     static constexpr int oDsig = oX + MT * XW;        // [MT] d sigma_raw
     static constexpr int oDdir = oDsig + MT;          // [MT][4] d view-direction from the SH colour
     static constexpr int oGo = oDdir + MT * 4;        // [MT][4] d sample position (= d ray origin contribution)
-    static constexpr int oRed = oGo + MT * 4;         // [16] reduction scratch
-    static constexpr int oAddr = oRed + 16;           // [MT] int ray id (or -1)
+    static constexpr int oAddr = oGo + MT * 4;        // [MT] int ray id (or -1)
     static constexpr int oZ = oAddr + MT;             // [MT] z value
     static constexpr int total = oZ + MT;
     static constexpr size_t bytes = (size_t)total * 4;
 };
 
-// acc (gradient wrt a post-ReLU activation) -> masked by (h > 0) -> LDS tile + dy_save.
+// acc (gradient wrt a post-ReLU activation) -> masked by the forward's ReLU bit mask -> LDS tile + dy_save.
+// The mask words are read with UNCONDITIONAL loads (row clamped): a predicated load is an exec-masked branch
+// that hipcc follows with a vmcnt(0) drain, i.e. one serialised memory round trip per load.
 template <int WIDTH, int NI, int MI>
-__device__ __forceinline__ void mask_store(f32x16 (&acc)[NI][MI], const float* __restrict__ hsave, float* __restrict__ dysave,
+__device__ __forceinline__ void mask_store(f32x16 (&acc)[NI][MI], const unsigned int* __restrict__ msave, float* __restrict__ dysave,
                                            float* X, int xw, int mrow0, int ncol0, long long row0, long long total, int lane) {
     const int r = lane & 31, h = lane >> 5;
+    unsigned wm[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const long long g = row0 + mrow0 + mi * 32 + r;
+            const long long gc = g < total ? g : total - 1;
+            wm[ni][mi] = msave[(size_t)gc * (WIDTH / 32) + (ncol0 >> 5) + ni];
+        }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -42,11 +52,10 @@ __device__ __forceinline__ void mask_store(f32x16 (&acc)[NI][MI], const float* _
             for (int mi = 0; mi < MI; ++mi) {
                 const int m = mrow0 + mi * 32 + r;
                 const bool ok = row0 + m < total;
-                f32x4 hv = {0.f, 0.f, 0.f, 0.f};
-                if (ok) hv = *reinterpret_cast<const f32x4*>(hsave + (size_t)(row0 + m) * WIDTH + k4);
+                const unsigned w = ok ? wm[ni][mi] >> (8 * q + 4 * h) : 0u;
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = hv[e] > 0.f ? acc[ni][mi][4 * q + e] : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = ((w >> e) & 1u) ? acc[ni][mi][4 * q + e] : 0.f;
                 *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, k4 >> 2, xw)]) = v;
                 if (ok) *reinterpret_cast<f32x4*>(dysave + (size_t)(row0 + m) * WIDTH + k4) = v;
             }
@@ -65,7 +74,6 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     float* sdsig = smem + SM::oDsig;
     float* sddir = smem + SM::oDdir;
     float* sgo = smem + SM::oGo;
-    float* sred = smem + SM::oRed;
     int* sray = reinterpret_cast<int*>(smem + SM::oAddr);
     float* sz = smem + SM::oZ;
 
@@ -82,7 +90,6 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     const size_t AS = a.act_stride;
 
     // ---- per-sample prologue: sigmoid and SH backward -> dsh (the dY of sh.2), d sigma, d dir
-    float bs2_part = 0.f;
     for (int m = tid; m < MT; m += NT) {
         const long long g = row0 + m;
         __attribute__((aligned(16))) float dsh[MCN_NSHP];
@@ -117,6 +124,7 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
                 ddy += dpre * (-C1 * s[1] + C20 * x * s[4] - C20 * z * s[5] - 2.f * C22 * y * s[6] - 2.f * C24 * y * s[8]);
                 ddz += dpre * (C1 * s[2] - C20 * y * s[5] + 4.f * C22 * z * s[6] - C20 * x * s[7]);
             }
+            dsh[MCN_NSH] = dsg;      // spare column 27 carries d sigma: the dW kernel reduces d sigma.2.{weight,bias} from it
             float* dst = a.dsh_save + (size_t)g * MCN_NSHP;
 #pragma unroll
             for (int i = 0; i < MCN_NSHP; i += 4) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<f32x4*>(&dsh[i]);
@@ -126,7 +134,6 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, c4, XW)]) = *reinterpret_cast<f32x4*>(&dsh[4 * c4]);
         sdsig[m] = dsg; sray[m] = ray; sz[m] = zv;
         sddir[m * 4] = ddx; sddir[m * 4 + 1] = ddy; sddir[m * 4 + 2] = ddz; sddir[m * 4 + 3] = 0.f;
-        bs2_part += dsg;
     }
     __syncthreads();
 
@@ -135,40 +142,35 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     mcn_zero<NI, MI>(acc);
     mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_NSHP / 8, pk + (L.bC2 >> 2) + (wn * NI) * (MCN_NSHP / 8) * 64, lane);
     __syncthreads();
-    mask_store<WIDTH, NI, MI>(acc, a.act_save + (size_t)(D + 1) * AS, a.dy_save + (size_t)(D + 1) * AS, X, XW, mrow0, ncol0, row0, total, lane);
+    mask_store<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(D + 1) * (AS / 32), a.dy_save + (size_t)(D + 1) * AS, X, XW, mrow0, ncol0, row0, total, lane);
     __syncthreads();
     // ---- sh.0^T and sigma.0^T both feed d h_{D-1}
     mcn_zero<NI, MI>(acc);
     mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, NSH, pk + (L.bC1 >> 2) + (wn * NI) * NSH * 64, lane);
     __syncthreads();
-    {   // dY of sigma.0 = d sigma * w_sigma2 masked by hs > 0 (outer product, no GEMM); also d w_sigma2
-        const float* hs = a.act_save + (size_t)D * AS;
+    {   // dY of sigma.0 = d sigma * w_sigma2 masked by hs > 0 (outer product, no GEMM)
+        const unsigned int* hm = a.mask_save + (size_t)D * (AS / 32);
         float* dys = a.dy_save + (size_t)D * AS;
         const float* w2 = prm + L.pWs2;
         constexpr int MG = NT / W4;             // sample groups (threads / chunks per row)
         const int c4 = tid % W4, mg = tid / W4;
         const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + 4 * c4);
-        f32x4 gw = {0.f, 0.f, 0.f, 0.f};
         for (int m = mg; m < MT; m += MG) {
             const bool ok = row0 + m < total;
-            f32x4 hv = {0.f, 0.f, 0.f, 0.f};
-            if (ok) hv = *reinterpret_cast<const f32x4*>(hs + (size_t)(row0 + m) * WIDTH + 4 * c4);
-            const float ds = sdsig[m];
+            const long long gc = ok ? row0 + m : total - 1;
+            const unsigned w = hm[(size_t)gc * (WIDTH / 32) + (c4 >> 3)] >> (4 * (c4 & 7));
+            const float ds = ok ? sdsig[m] : 0.f;
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = hv[e] > 0.f ? ds * ww[e] : 0.f; gw[e] = fmaf(ds, hv[e], gw[e]); }
+            for (int e = 0; e < 4; ++e) v[e] = ((w >> e) & 1u) ? ds * ww[e] : 0.f;
             *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, c4, XW)]) = v;
             if (ok) *reinterpret_cast<f32x4*>(dys + (size_t)(row0 + m) * WIDTH + 4 * c4) = v;
-        }
-        if (a.grads) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(a.grads + L.pWs2 + 4 * c4 + e, gw[e]);
         }
     }
     __syncthreads();
     mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, NSH, pk + (L.bS1 >> 2) + (wn * NI) * NSH * 64, lane);
     __syncthreads();
-    mask_store<WIDTH, NI, MI>(acc, a.act_save + (size_t)(D - 1) * AS, a.dy_save + (size_t)(D - 1) * AS, X, XW, mrow0, ncol0, row0, total, lane);
+    mask_store<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(D - 1) * (AS / 32), a.dy_save + (size_t)(D - 1) * AS, X, XW, mrow0, ncol0, row0, total, lane);
     __syncthreads();
 
     // ---- trunk, last layer to first.  X holds dY_l; the encoded-input gradient accumulates in denc.
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
         mcn_zero<NI, MI>(acc);
         mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, NSH, pk + (L.bH[l] >> 2) + (wn * NI) * NSH * 64, lane);
         __syncthreads();
-        mask_store<WIDTH, NI, MI>(acc, a.act_save + (size_t)(l - 1) * AS, a.dy_save + (size_t)(l - 1) * AS, X, XW, mrow0, ncol0, row0, total, lane);
+        mask_store<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(l - 1) * (AS / 32), a.dy_save + (size_t)(l - 1) * AS, X, XW, mrow0, ncol0, row0, total, lane);
         __syncthreads();
     }
     __syncthreads();
@@ -253,19 +255,6 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
                 if (a.d_rays_o) atomicAdd(a.d_rays_o + ray * 3 + c, so[c]);
                 if (a.d_rays_d) atomicAdd(a.d_rays_d + ray * 3 + c, sd[c]);
             }
-        }
-    }
-    // ---- d bias of sigma.2 = sum of d sigma over the tile
-    if (a.grads) {
-        float v = bs2_part;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) sred[wave] = v;
-        __syncthreads();
-        if (tid == 0) {
-            float s = 0.f;
-            for (int w = 0; w < WAVES; ++w) s += sred[w];
-            atomicAdd(a.grads + L.pBs2, s);
         }
     }
 }

@@ -5,21 +5,20 @@
 // (model/net_block.py:51-65).  The reduction runs over samples, so each workgroup takes a chunk of
 // rows, keeps its full (wave-tiled) dW block in MFMA accumulators for the whole chunk and issues one
 // float-atomic pass at the end (>= 512 FLOP per atomic byte, far above the atomic roofline).
-// Operands stream straight from HBM/L2 into registers: per two sample rows a lane loads VN
-// consecutive dY values (the n index is interleaved over the VN n-tiles so this is one vector load)
-// and KT separate X values (k contiguous per tile, so the final atomics are 128-byte row segments).
+// (Design notes at the kernel.)
 #include "mcnerf_common.h"
 #include "mcnerf_kernels.h"
 
 struct DwSeg {
     const float* dY; int ldy;     // [rows][ldy], columns nbase.. are the outputs
     const float* X;  int ldx;     // [rows][ldx]
-    int N, n_real;                // padded / real output count
+    int N, n_lo, n_real;          // padded output count; outputs n_lo <= n < n_real are real (row n - n_lo of dW)
     int K, k_real;                // padded / real input count
     float* dW; int ldw;           // destination (already offset to the segment's first column)
     float* db;                    // bias gradient or null
 };
 
+#define DW_SLAB_ROWS 16
 template <int V> struct VecT;
 template <> struct VecT<1> { typedef float T; };
 template <> struct VecT<2> { typedef float T __attribute__((ext_vector_type(2))); };
@@ -27,20 +26,45 @@ template <> struct VecT<4> { typedef float T __attribute__((ext_vector_type(4)))
 template <int V> __device__ __forceinline__ float vget(const typename VecT<V>::T& v, int i) { return v[i]; }
 template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
 
-template <int VN, int KT>
-__global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int rows_cap, int rows_per_wg) {
+// One workgroup = 8 waves, PERSISTENT: the grid is one workgroup per CU and each takes a contiguous
+// chunk of ceil(rows / grid) rows, so the float-atomic epilogue (the full dW block, 256 KB at width 256)
+// is paid once per CU instead of once per 1024 rows (the chip-wide atomic rate is only ~1.3 TB/s).
+// Operands are staged through LDS in slabs of RS rows (LDS-DMA into a 3-deep ring, one raw barrier per
+// slab, counted vmcnt): every dY / X row is fetched from HBM once per workgroup and shared by the 8 waves,
+// instead of each wave re-fetching its fragments (4x / 2x redundant) through the L1.
+//   wave tile = (32*VN) outputs x (32*KT) inputs; lane (r = lane&31, h = lane>>5) owns outputs
+//   nbase + VN*r + t (interleaved, so its A fragment is ONE ds_read of VN floats) and inputs
+//   kbase + 32*kt + r (contiguous per tile, so the final atomics are 128-byte row segments).
+template <int N, int K>
+__global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int rows_cap) {
+    // N, K (padded output / input counts) are compile-time so that the slab copy is a fixed, branch-free
+    // sequence (a runtime-predicated load is an exec-masked branch and serialises on vmcnt(0))
+    constexpr int VN = N >= 128 ? 4 : N / 32;
+    constexpr int KT = N == 32 ? (K >= 128 ? 4 : K / 32) : (K >= 64 ? 2 : 1);
     typedef typename VecT<VN>::T AV;
+    constexpr int RS = DW_SLAB_ROWS;               // rows per slab (8 MFMA k-steps of 2 rows)
+    // LDS ring of 3 slabs: slab s is consumed while slab s+2 is in flight
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int rows = count ? min(*count, rows_cap) : rows_cap;
-    const int r0 = blockIdx.x * rows_per_wg;
+    int chunk = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+    chunk = (chunk + RS - 1) / RS * RS;
+    const int r0 = blockIdx.x * chunk;
     if (r0 >= rows) return;
-    const int r1 = min(r0 + rows_per_wg, rows);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r1 = min(r0 + chunk, rows);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int NG = s.N / (32 * VN), KG = s.K / (32 * KT);
-    const int G = NG * KG;                  // wave tiles per workgroup; the remaining factor splits rows
-    const int MS = 8 / G;
+    constexpr int NG = N / (32 * VN), KG = K / (32 * KT);
+    constexpr int G = NG * KG;              // wave tiles per workgroup; the remaining factor splits the slab rows
+    constexpr int MS = 8 / G;
+    static_assert(G >= 1 && G <= 8 && 8 % G == 0, "wave tiling");
+    constexpr int PP = RS / 2 / MS;         // row pairs per wave per slab
+    static_assert(PP >= 1, "slab too small for the row split");
     const int gi = wave % G, ms = wave / G;
     const int nbase = (gi % NG) * 32 * VN, kbase = (gi / NG) * 32 * KT;
+    constexpr int slab = RS * (N + K);      // floats per buffer: sY[RS][N] then sX[RS][K]
+    constexpr int n4 = N / 4, k4 = K / 4;
+    constexpr int tot4 = RS * (n4 + k4);    // float4 per slab
+    constexpr int NP = (tot4 + 511) / 512;  // LDS-DMA pieces (wave-instructions) per wave per slab
 
     f32x16 acc[VN][KT];
     mcn_zero<VN, KT>(acc);
@@ -48,31 +72,76 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
 #pragma unroll
     for (int t = 0; t < VN; ++t) bsum[t] = 0.f;
 
-    const float* pa = s.dY + nbase + VN * r;
-    const float* pb = s.X + kbase + r;
-    // Register pipeline: PF row pairs in flight per wave (HBM latency ~2 us vs 8 MFMAs = 0.2 us per pair).
-    constexpr int PF = 8;
-    AV av[PF];
-    float bv[PF][KT];
-    const int stride = 2 * MS;
-    auto load = [&](AV& a_dst, float (&b_dst)[KT], int mrow) {
-        const int row = mrow + h;
-        const bool ok = row < r1;
-        if (ok) a_dst = *reinterpret_cast<const AV*>(pa + (size_t)row * s.ldy); else a_dst = AV(0.f);
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) b_dst[kt] = ok ? pb[(size_t)row * s.ldx + 32 * kt] : 0.f;
+    // Slab rows -> LDS by LDS-DMA (global_load_lds, 16 B per lane): no staging registers.  The destination of
+    // one wave-instruction is wave-uniform base + lane*16, i.e. exactly the linear slab image (float4 index
+    // q = tid + i*512).  Rows beyond the chunk are clamped to its last row (finite data) and neutralised by
+    // zeroing the A fragment when it is read.  (Segment fields are copied to locals: a by-reference capture of
+    // the kernel-argument struct makes hipcc re-read it with ordinary global loads inside the loop, and any
+    // such load next to LDS-DMA drains vmcnt(0).)
+    const float* const gY = s.dY;
+    const float* const gX = s.X;
+    const int ldy = s.ldy, ldx = s.ldx;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    auto piece = [=](int i, int base_row, float* buf) {
+        const int q = tid + i * 512;
+        if ((i + 1) * 512 <= tot4 || q < tot4) {
+            const bool isY = q < RS * n4;
+            const int qq = isY ? q : q - RS * n4;
+            const int w4 = isY ? n4 : k4;
+            const int row = qq / w4, c4 = qq - row * w4;
+            const int grow = base_row + row;
+            const int rc = grow < r1 ? grow : r1 - 1;
+            const float* src = isY ? gY + (size_t)rc * ldy + 4 * c4 : gX + (size_t)rc * ldx + 4 * c4;
+            float* dst = buf + 4 * (i * 512 + (tid & ~63));                // wave-uniform; the lane offset is implicit
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        }
     };
-    int m = r0 + 2 * ms;
+    // All VMEM operations of the main loop are these pieces, NP per slab per wave, in program order, so
+    // "slab s+1 has landed" == at most NP (the pieces of slab s+2) still outstanding: counted vmcnt + raw
+    // s_barrier (a __syncthreads() would drain vmcnt(0) and expose the HBM latency every slab).
+#define DW_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n) : "memory")
+    float* b_cur = lds;
+    float* b_nxt = lds + slab;
+    float* b_fill = lds + 2 * slab;
 #pragma unroll
-    for (int p = 0; p < PF; ++p) load(av[p], bv[p], m + p * stride);
-    for (; m < r1; m += PF * stride) {
+    for (int i = 0; i < NP; ++i) piece(i, r0, b_cur);
+    if (r0 + RS < r1) {
 #pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const AV a_c = av[p];
+        for (int i = 0; i < NP; ++i) piece(i, r0 + RS, b_nxt);
+        DW_WAIT_BARRIER(NP);
+    } else {
+        DW_WAIT_BARRIER(0);
+    }
+    for (int base = r0; base < r1; base += RS) {
+        const bool fill = base + 2 * RS < r1;          // workgroup-uniform
+        const float* sY = b_cur;
+        const float* sX = sY + RS * N;
+        // operand fragments are read from LDS one row pair ahead of the MFMAs that use them
+        AV a_n = *reinterpret_cast<const AV*>(sY + (2 * ms + h) * N + nbase + VN * r);
+        float b_n[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) b_n[kt] = sX[(2 * ms + h) * K + kbase + 32 * kt + r];
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {              // row pair p: lanes h=0 take row 2p, h=1 row 2p+1
+            const int row = 2 * (ms + pp * MS) + h;
+            AV a_c = a_n;
             float b_c[KT];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) b_c[kt] = bv[p][kt];
-            load(av[p], bv[p], m + (p + PF) * stride);          // refill the slot for PF pairs later
+            for (int kt = 0; kt < KT; ++kt) b_c[kt] = b_n[kt];
+            if (pp + 1 < PP) {
+                const int rown = row + 2 * MS;
+                a_n = *reinterpret_cast<const AV*>(sY + rown * N + nbase + VN * r);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) b_n[kt] = sX[rown * K + kbase + 32 * kt + r];
+            }
+            if (fill) {                                // this slab's share of the DMA, spread between the MFMA groups
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    if ((i * PP) / NP == pp) piece(i, base + 2 * RS, b_fill);
+            }
+            if (base + row >= r1) a_c = AV(0.f);
+            __builtin_amdgcn_sched_barrier(0);         // keep the next pair's LDS reads ABOVE this pair's MFMAs
 #pragma unroll
             for (int t = 0; t < VN; ++t) {
                 const float a1 = vget<VN>(a_c, t);
@@ -81,7 +150,11 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
                 for (int kt = 0; kt < KT; ++kt) acc[t][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b_c[kt], acc[t][kt], 0, 0, 0);
             }
         }
+        // everyone is done reading b_cur; slab base+RS (in b_nxt) has landed for every wave
+        if (fill) DW_WAIT_BARRIER(NP); else DW_WAIT_BARRIER(0);
+        float* t = b_cur; b_cur = b_nxt; b_nxt = b_fill; b_fill = t;
     }
+#undef DW_WAIT_BARRIER
     // accumulators -> global (float atomics; one register = two 128-byte row segments)
 #pragma unroll
     for (int t = 0; t < VN; ++t)
@@ -91,7 +164,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = nbase + VN * ((e & 3) + 8 * (e >> 2) + 4 * h) + t;
-                if (n < s.n_real && k < s.k_real) atomicAdd(s.dW + (size_t)n * s.ldw + k, acc[t][kt][e]);
+                if (n >= s.n_lo && n < s.n_real && k < s.k_real) atomicAdd(s.dW + (size_t)(n - s.n_lo) * s.ldw + k, acc[t][kt][e]);
             }
         }
     if (s.db && kbase == 0) {
@@ -99,26 +172,48 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
         for (int t = 0; t < VN; ++t) {
             const float b = bsum[t] + __shfl_xor(bsum[t], 32);
             const int n = nbase + VN * r + t;
-            if (h == 0 && n < s.n_real) atomicAdd(s.db + n, b);
+            if (h == 0 && n >= s.n_lo && n < s.n_real) atomicAdd(s.db + (n - s.n_lo), b);
         }
     }
 }
 
+static int dw_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 static hipError_t launch_seg(const DwSeg& s, const int* count, int rows_cap, hipStream_t st) {
-    const int rows_per_wg = 1024;
-    const int grid = (rows_cap + rows_per_wg - 1) / rows_per_wg;
-    if (grid <= 0) return hipSuccess;
-    const int vn = s.N >= 128 ? 4 : s.N / 32;
-    int kt;
-    if (s.N == 32) kt = s.K >= 128 ? 4 : s.K / 32;
-    else kt = s.K >= 64 ? 2 : 1;
-#define DW_LAUNCH(VN, KT) hipLaunchKernelGGL((dw_kernel<VN, KT>), dim3(grid), dim3(512), 0, st, s, count, rows_cap, rows_per_wg)
-    if (vn == 4 && kt == 2) DW_LAUNCH(4, 2);
-    else if (vn == 2 && kt == 2) DW_LAUNCH(2, 2);
-    else if (vn == 1 && kt == 1) DW_LAUNCH(1, 1);
-    else if (vn == 1 && kt == 2) DW_LAUNCH(1, 2);
-    else if (vn == 1 && kt == 4) DW_LAUNCH(1, 4);
-    else return hipErrorInvalidValue;
+    if (rows_cap <= 0) return hipSuccess;
+    int grid = dw_num_cus();                                   // persistent: one workgroup per CU
+    const int max_wgs = (rows_cap + DW_SLAB_ROWS - 1) / DW_SLAB_ROWS;
+    if (grid > max_wgs) grid = max_wgs;
+    const size_t lds = (size_t)3 * DW_SLAB_ROWS * (s.N + s.K) * sizeof(float);
+#define DW_LAUNCH(NN, KK) do { \
+        auto kern = dw_kernel<NN, KK>; \
+        if (lds > 64 * 1024) { \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e; \
+        } \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, s, count, rows_cap); } while (0)
+    const int key = s.N * 1000 + s.K;
+    switch (key) {
+        case 256256: DW_LAUNCH(256, 256); break;
+        case 256064: DW_LAUNCH(256, 64); break;
+        case 32256:  DW_LAUNCH(32, 256); break;
+        case 128128: DW_LAUNCH(128, 128); break;
+        case 128064: DW_LAUNCH(128, 64); break;
+        case 32128:  DW_LAUNCH(32, 128); break;
+        case 64064:  DW_LAUNCH(64, 64); break;
+        case 32064:  DW_LAUNCH(32, 64); break;
+        case 32032:  DW_LAUNCH(32, 32); break;
+        default: return hipErrorInvalidValue;
+    }
 #undef DW_LAUNCH
     return hipGetLastError();
 }
@@ -133,22 +228,25 @@ hipError_t mcn_launch_dw(const McnDwArgs& a, hipStream_t st) {
     for (int l = 0; l < D; ++l) {
         const int ldw = mcn_in_features(D, W, L.skip, l);
         if (l == 0 || l == L.skip) {      // encoded-input columns
-            DwSeg s = {dy(l), W, a.enc_save, MCN_ENCP, W, W, MCN_ENCP, MCN_ENC, a.grads + L.pW[l], ldw, a.grads + L.pB[l]};
+            DwSeg s = {dy(l), W, a.enc_save, MCN_ENCP, W, 0, W, MCN_ENCP, MCN_ENC, a.grads + L.pW[l], ldw, a.grads + L.pB[l]};
             if ((e = launch_seg(s, a.count, a.rows, st)) != hipSuccess) return e;
         }
         if (l > 0) {                      // hidden-input columns (after the 63 encoded ones at the skip layer)
-            DwSeg s = {dy(l), W, act(l - 1), W, W, W, W, W, a.grads + L.pW[l] + (l == L.skip ? MCN_ENC : 0), ldw,
+            DwSeg s = {dy(l), W, act(l - 1), W, W, 0, W, W, W, a.grads + L.pW[l] + (l == L.skip ? MCN_ENC : 0), ldw,
                        l == L.skip ? nullptr : a.grads + L.pB[l]};
             if ((e = launch_seg(s, a.count, a.rows, st)) != hipSuccess) return e;
         }
     }
     {   // sigma.0 and sh.0 read the last trunk activation; sh.2 reads the sh hidden layer
-        DwSeg s1 = {dy(D), W, act(D - 1), W, W, W, W, W, a.grads + L.pWs1, W, a.grads + L.pBs1};
+        DwSeg s1 = {dy(D), W, act(D - 1), W, W, 0, W, W, W, a.grads + L.pWs1, W, a.grads + L.pBs1};
         if ((e = launch_seg(s1, a.count, a.rows, st)) != hipSuccess) return e;
-        DwSeg c1 = {dy(D + 1), W, act(D - 1), W, W, W, W, W, a.grads + L.pWc1, W, a.grads + L.pBc1};
+        DwSeg c1 = {dy(D + 1), W, act(D - 1), W, W, 0, W, W, W, a.grads + L.pWc1, W, a.grads + L.pBc1};
         if ((e = launch_seg(c1, a.count, a.rows, st)) != hipSuccess) return e;
-        DwSeg c2 = {a.dsh_save, MCN_NSHP, act(D + 1), W, MCN_NSHP, MCN_NSH, W, W, a.grads + L.pWc2, W, a.grads + L.pBc2};
+        DwSeg c2 = {a.dsh_save, MCN_NSHP, act(D + 1), W, MCN_NSHP, 0, MCN_NSH, W, W, a.grads + L.pWc2, W, a.grads + L.pBc2};
         if ((e = launch_seg(c2, a.count, a.rows, st)) != hipSuccess) return e;
+        // sigma.2 (1 x W): d sigma sits in the spare column 27 of dsh_save, its input is the sigma hidden layer
+        DwSeg s2 = {a.dsh_save, MCN_NSHP, act(D), W, MCN_NSHP, MCN_NSH, MCN_NSH + 1, W, W, a.grads + L.pWs2, W, a.grads + L.pBs2};
+        if ((e = launch_seg(s2, a.count, a.rows, st)) != hipSuccess) return e;
     }
     return hipSuccess;
 }

@@ -5,7 +5,7 @@
 // (model/mc_nerf.py:688-701), SinCosEmbedding.forward (model/net_block.py:20-35),
 // CorseFine_NeRF.forward (model/net_block.py:67-78) and eval_sh (model/net_utils.py:103-191).
 //
-// One workgroup = 8 waves = one tile of MT samples.  Per layer each wave accumulates its
+// One workgroup = WN x WM waves (4 at widths 128/256) = one tile of MT samples (64), two workgroups per CU.  Per layer each wave accumulates its
 // (NI x MI) 32x32 output tiles with v_mfma_f32_32x32x2_f32 (exact fp32), weight fragments streamed
 // from L2 in packed order, activation fragments read from the swizzled LDS tile; the layer output
 // (bias + ReLU) is written back in place after a barrier.
@@ -47,6 +47,51 @@ __device__ __forceinline__ void write_encoding(float* X, const float* sxyz, cons
         const int m = it >> 2, c = it & 3;
         X[mcn_swz(m, c == 3 ? 63 : c, XW)] = (c == 3) ? 0.f : sxyz[m * 4 + c];
     }
+}
+
+// Layer epilogue shared by the trunk layers and the two head hidden layers: v = relu(acc + bias);
+//   TO_LDS : write v into the LDS tile (next layer's input)
+//   SAVE   : store v (dW operand) and its 1-bit ReLU mask (backward chain) to the workspaces
+//   DOT    : accumulate sum_n v[n] * w2[n] per sample (the 1-wide sigma output layer, lane-local)
+// A lane holds 16 of the 32 columns of its row per tile (the other 16 sit in lane ^ 32), so the mask halves
+// are combined with one cross-lane move.
+template <int WIDTH, int NI, int MI, bool TO_LDS, bool SAVE, bool DOT>
+__device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NI][MI], const float* __restrict__ bias, const float* __restrict__ w2,
+                                               float* X, int xw, float* __restrict__ save, unsigned int* __restrict__ msave,
+                                               float (&dot)[MI], int mrow0, int ncol0, long long row0, long long total, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) dot[mi] = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = mrow0 + mi * 32 + r;
+            const bool ok = row0 + m < total;
+            unsigned bits = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n4 = ncol0 + ni * 32 + 8 * q + 4 * h;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n4);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[ni][mi][4 * q + e] + bb[e], 0.f);
+                    if (SAVE) bits |= (v[e] > 0.f ? 1u : 0u) << (8 * q + 4 * h + e);
+                }
+                if (DOT) {
+                    const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + n4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dot[mi] = fmaf(v[e], ww[e], dot[mi]);
+                }
+                if (TO_LDS) *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, n4 >> 2, xw)]) = v;
+                if (SAVE && ok) *reinterpret_cast<f32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = v;
+            }
+            if (SAVE) {
+                const unsigned w = bits | (unsigned)__shfl_xor((int)bits, 32);
+                if (h == 0 && ok) msave[(size_t)(row0 + m) * (WIDTH / 32) + (ncol0 >> 5) + ni] = w;
+            }
+        }
 }
 
 template <int WIDTH, bool SAVE>
@@ -125,25 +170,10 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             }
         }
         __syncthreads();
-        const float* bias = prm + L.pB[l];
-        float* save = SAVE ? a.act_save + (size_t)l * a.act_stride : nullptr;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n4 = ncol0 + ni * 32 + 8 * q + 4 * h;
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n4);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int m = mrow0 + mi * 32 + r;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[ni][mi][4 * q + e] + bb[e], 0.f);
-                    *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, n4 >> 2, XW)]) = v;
-                    if (SAVE && row0 + m < total)
-                        *reinterpret_cast<f32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = v;
-                }
-            }
+        float unused[MI];
+        layer_epilogue<WIDTH, NI, MI, true, SAVE, false>(acc, prm + L.pB[l], nullptr, X, XW,
+            SAVE ? a.act_save + (size_t)l * a.act_stride : nullptr,
+            SAVE ? a.mask_save + (size_t)l * (a.act_stride / 32) : nullptr, unused, mrow0, ncol0, row0, total, lane);
         __syncthreads();
     }
 
@@ -151,32 +181,10 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     {
         mcn_zero<NI, MI>(acc);
         mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, KSH, pk + (L.fS1 >> 2) + (wn * NI) * KSH * 64, lane);
-        const float* bias = prm + L.pBs1;
-        const float* w2 = prm + L.pWs2;
-        float* save = SAVE ? a.act_save + (size_t)L.depth * a.act_stride : nullptr;
         float s[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) s[mi] = 0.f;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n4 = ncol0 + ni * 32 + 8 * q + 4 * h;
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n4);
-                const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + n4);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = fmaxf(acc[ni][mi][4 * q + e] + bb[e], 0.f);
-                        s[mi] = fmaf(v[e], ww[e], s[mi]);
-                    }
-                    const int m = mrow0 + mi * 32 + r;
-                    if (SAVE && row0 + m < total)
-                        *reinterpret_cast<f32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = v;
-                }
-            }
+        layer_epilogue<WIDTH, NI, MI, false, SAVE, true>(acc, prm + L.pBs1, prm + L.pWs2, X, XW,
+            SAVE ? a.act_save + (size_t)L.depth * a.act_stride : nullptr,
+            SAVE ? a.mask_save + (size_t)L.depth * (a.act_stride / 32) : nullptr, s, mrow0, ncol0, row0, total, lane);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             s[mi] += __shfl_xor(s[mi], 32);
@@ -188,25 +196,10 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
         mcn_zero<NI, MI>(acc);
         mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, KSH, pk + (L.fC1 >> 2) + (wn * NI) * KSH * 64, lane);
         __syncthreads();
-        const float* bias = prm + L.pBc1;
-        float* save = SAVE ? a.act_save + (size_t)(L.depth + 1) * a.act_stride : nullptr;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n4 = ncol0 + ni * 32 + 8 * q + 4 * h;
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n4);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int m = mrow0 + mi * 32 + r;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[ni][mi][4 * q + e] + bb[e], 0.f);
-                    *reinterpret_cast<f32x4*>(&X[mcn_swz_chunk(m, n4 >> 2, XW)]) = v;
-                    if (SAVE && row0 + m < total)
-                        *reinterpret_cast<f32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = v;
-                }
-            }
+        float unused[MI];
+        layer_epilogue<WIDTH, NI, MI, true, SAVE, false>(acc, prm + L.pBc1, nullptr, X, XW,
+            SAVE ? a.act_save + (size_t)(L.depth + 1) * a.act_stride : nullptr,
+            SAVE ? a.mask_save + (size_t)(L.depth + 1) * (a.act_stride / 32) : nullptr, unused, mrow0, ncol0, row0, total, lane);
         __syncthreads();
     }
     // ---- SH output layer (27 -> 32 padded outputs): one 32-row m-tile per wave

@@ -135,7 +135,7 @@ class RenderTrainFn(torch.autograd.Function):
             d_out = ops.composite_bwd(out, zgrid, jit, eps, d_rgb.contiguous(), st.white_back)
             dy = torch.empty_like(save.act)
             dsh = torch.empty_like(save.sh)
-            ops.mlp_bwd(net, flat, packed, rays_o, rays_d, zgrid, jit, barf_w, out, d_out, save, grads, dy, dsh,
+            ops.mlp_bwd(net, flat, packed, rays_o, rays_d, zgrid, jit, barf_w, out, d_out, save, dy, dsh,
                         d_o, d_d, idx=idx, count=count, max_rows=max_rows)
             rows = max_rows if idx is not None else N * zgrid.numel()
             ops.mlp_dw(net, save, dy, dsh, grads, rows, count=count)

@@ -129,6 +129,7 @@ class MlpSave:
     act: Tensor
     enc: Tensor
     sh: Tensor
+    mask: Tensor
 
 
 def alloc_save(net: Net, capacity: int, device) -> MlpSave:
@@ -136,7 +137,8 @@ def alloc_save(net: Net, capacity: int, device) -> MlpSave:
     return MlpSave(capacity,
                    torch.empty((net.depth + 2) * capacity * net.width, dtype=torch.float32, device=device),
                    torch.empty(capacity * 64, dtype=torch.float32, device=device),
-                   torch.empty(capacity * 32, dtype=torch.float32, device=device))
+                   torch.empty(capacity * 32, dtype=torch.float32, device=device),
+                   torch.empty((net.depth + 2) * capacity * (net.width // 32), dtype=torch.int32, device=device))
 
 
 def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, zgrid: Tensor,
@@ -147,18 +149,19 @@ def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
     _lib.call("mcnerf_mlp_fwd", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
               _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
               _p(out), _p(save.act) if save else None, save.capacity if save else 0,
-              _p(save.enc) if save else None, _p(save.sh) if save else None, _stream())
+              _p(save.enc) if save else None, _p(save.sh) if save else None,
+              _p(save.mask, torch.int32) if save else None, _stream())
 
 
 def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, zgrid: Tensor,
             jitter: Optional[Tensor], barf_w: Tensor, out: Tensor, d_out: Tensor, save: MlpSave,
-            grads: Optional[Tensor], dy: Tensor, dsh: Tensor, d_rays_o: Optional[Tensor], d_rays_d: Optional[Tensor],
+            dy: Tensor, dsh: Tensor, d_rays_o: Optional[Tensor], d_rays_d: Optional[Tensor],
             idx: Optional[Tensor] = None, count: Optional[Tensor] = None, max_rows: int = 0) -> None:
     n_rays, S = rays_d.shape[0], zgrid.numel()
     _lib.call("mcnerf_mlp_bwd", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
               _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
-              _p(out), _p(d_out), _p(save.act), save.capacity, _p(save.enc), _p(save.sh),
-              _p(grads), _p(dy), _p(dsh), _p(d_rays_o), _p(d_rays_d), _stream())
+              _p(out), _p(d_out), _p(save.mask, torch.int32), save.capacity, _p(save.enc), _p(save.sh),
+              _p(dy), _p(dsh), _p(d_rays_o), _p(d_rays_d), _stream())
 
 
 def mlp_dw(net: Net, save: MlpSave, dy: Tensor, dsh: Tensor, grads: Tensor, rows: int,

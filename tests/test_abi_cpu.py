@@ -49,7 +49,7 @@ def test_layout_queries_need_no_gpu(built_lib):
     assert 102428 <= ops.param_count(coarse) <= 102428 + 4 * 18
     offs = ops.param_offsets(fine)
     assert offs[0] == 0 and all(b > a for a, b in zip(offs, offs[1:])) and all(o % 4 == 0 for o in offs)
-    assert ops.tile_rows(256) == 128
+    assert ops.tile_rows(256) == 64
     assert ops._lib.lib().mcnerf_param_count(3, 100, 1) == -1   # unsupported width
 
 

@@ -1,0 +1,146 @@
+"""The N > 1 path on CPU: two gloo ranks exercise the camera sharding, the parameter broadcast and the
+single flat-buffer gradient all-reduce (mc_nerf_amd/distributed.py) with the real MC_Model on the CPU
+(stage 1 of training - camera parameters only - needs no render, so its forward/backward run here)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_cameras_partitions_like_distributed_sampler():
+    from mc_nerf_amd.distributed import shard_cameras
+    for world in (1, 2, 4, 8):
+        seen = []
+        lens = set()
+        for r in range(world):
+            ids = shard_cameras(110, epoch=3, rank=r, world=world, seed=42)
+            lens.add(len(ids))
+            seen += ids
+        assert len(lens) == 1                                  # every rank takes the same number of steps
+        assert set(seen) == set(range(110))                    # all cameras covered (padding repeats a few)
+        assert len(seen) == ((110 + world - 1) // world) * world
+    assert shard_cameras(110, 0, 0, 2, seed=1) != shard_cameras(110, 1, 0, 2, seed=1)   # set_epoch reshuffles
+
+
+def _build_model(batch=64):
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd.model import MC_Model
+    sp = S.make_sys_param("cpu", samples=32, scale=2, batch=batch, H=16, W=16, coarse=(4, 32, [2]), fine=(8, 64, [4]))
+    torch.manual_seed(0)
+    m = MC_Model(sp)
+    # the per-step validation rays come from the HIP ray generator (no CPU path, by design): stub them out here,
+    # this file tests the data-parallel plumbing only
+    m.get_rays = lambda pose, img_id, intr_inv: (torch.zeros(256, 3), torch.zeros(256, 3))
+    return m, sp
+
+
+def _stage1_grads(model, sp, cam, calib):
+    from mc_nerf_amd.model import MC_NeRF_Loss
+    wpts, pts = calib
+    data = (torch.zeros(1, 256, 3), torch.tensor([cam]), wpts, pts, wpts, pts)
+    for p in model.parameters():
+        p.grad = None
+    loss_dict, *_ = model(data, 0, "CAM_PARAM_EPOCH", 0.0)
+    MC_NeRF_Loss(sp)(loss_dict, "CAM_PARAM_EPOCH").backward()
+    return {n: (p.grad.clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+
+
+def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except Exception as e:                       # surface the failure instead of a queue timeout
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None))
+        raise
+
+
+def _worker_body(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from mc_nerf_amd import distributed as D
+    from mc_nerf_amd import synthetic as S
+    r, w, dev = D.init_distributed(backend="gloo")
+    assert (r, w, dev.type) == (rank, world, "cpu")
+    model, sp = _build_model()
+    S.init_cameras_near_gt(model, noise=0.01, seed=rank)       # ranks start different ...
+    with torch.no_grad():
+        for p in model.nerf.parameters():
+            p.add_(float(rank))
+    sync = D.FlatGradSync(model, world)
+    sync.broadcast_parameters()                                # ... and must leave equal to rank 0
+    chk = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    ref = chk.clone()
+    dist.broadcast(ref, src=0)
+    same_after_bcast = bool(torch.equal(chk, ref))
+    calib = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0])
+    cam = D.shard_cameras(model.train_numb, 0, rank, world, seed=1)[0]
+    sync.prepare()
+    mine = _stage1_grads(model, sp, cam, calib)
+    # NeRF weights have no gradient in stage 1; give two of them synthetic ones to exercise the gather path
+    for name, p in list(model.nerf.named_parameters())[:2]:
+        p.grad = torch.full_like(p, float(rank + 1))
+        mine["nerf." + name] = p.grad.clone()
+    sync.sync()
+    out = {n: (p.grad.clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    as_np = lambda d: {k: (None if v is None else v.numpy().copy()) for k, v in d.items()}   # pickle by value
+    q.put((rank, same_after_bcast, as_np(mine), as_np(out)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_flat_allreduce_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for r in res:
+        assert r[1] != "error", r[2]
+    res = sorted(res, key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, mine0, out0), (_, b1, mine1, out1) = res
+    assert b0 and b1
+    n_checked = 0
+    for name in out0:
+        if mine0[name] is None and mine1[name] is None:
+            assert out0[name] is None
+            continue
+        mean = (mine0[name] + mine1[name]) / 2                 # DDP semantics: SUM then divide by the world size
+        assert abs(out0[name] - mean).max() <= 1e-6, name
+        assert (out0[name] == out1[name]).all(), name           # both ranks hold identical averaged gradients
+        n_checked += 1
+    assert n_checked >= 8                                       # 6 camera tensors + the 2 synthetic NeRF gradients
+
+
+def test_single_process_sync_is_identity():
+    from mc_nerf_amd import distributed as D
+    from mc_nerf_amd import synthetic as S
+    model, sp = _build_model()
+    S.init_cameras_near_gt(model)
+    sync = D.FlatGradSync(model, 1)
+    calib = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0])
+    sync.prepare()
+    g = _stage1_grads(model, sp, 3, calib)
+    sync.sync()
+    for n, p in model.named_parameters():
+        if g[n] is not None:
+            assert torch.equal(p.grad, g[n])
+    assert sync.arena.numel() == sum(p.numel() for _, p in model.named_parameters() if not _.startswith("nerf.")) + \
+        sum(n.flat_params().numel() for n in sync.nets)

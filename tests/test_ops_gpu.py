@@ -205,7 +205,7 @@ def test_mlp_fwd_bwd_indexed(gpu_device, width):
     dsh = torch.empty_like(save.sh)
     d_o = torch.zeros(N, 3, device=dev)
     d_d = torch.zeros(N, 3, device=dev)
-    ops.mlp_bwd(net, flat, packed, od, dd, zd, jd, bw, out, d_out, save, grads, dy, dsh, d_o, d_d,
+    ops.mlp_bwd(net, flat, packed, od, dd, zd, jd, bw, out, d_out, save, dy, dsh, d_o, d_d,
                 idx=idx_d, count=count, max_rows=cap)
     ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count)
     torch.cuda.synchronize()
