@@ -166,6 +166,18 @@ def main():
         kern_ms = {k: v[0] for k, v in cand.items() if v[0]}
         dom = max(kern_ms, key=kern_ms.get)
         ach = cand[dom][1] / (cand[dom][0] * 1e-3) / 1e12
+        # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes of this same command, collected and
+        # corrected as MI355X_MICROARCH.md prescribes (see profiles/*_pmc_traffic.json for the method)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+        if os.path.exists(tpath) and args.rays == 32768:
+            names = {"mlp_fwd<256>": "mlp_fwd_kernel<256, true>", "mlp_bwd<256>": "mlp_bwd_kernel<256>"}
+            kern = json.load(open(tpath))["kernels"]
+            if dom in names and names[dom] in kern:
+                traffic = kern[names[dom]]["hbm_bytes_per_launch"]
+            elif dom == "mlp_dw<256>":
+                traffic = sum(v["hbm_bytes_per_launch"] * {"dw_kernel<256, 256>": 9, "dw_kernel<256, 64>": 2, "dw_kernel<32, 256>": 2}.get(k, 0)
+                              for k, v in kern.items())
         total_rays = args.rays * world * args.steps
         out = {
             "metric": "train rays/sec (coarse+fine, 64+128 samples)", "value": total_rays / dt, "unit": "rays/s",
@@ -176,7 +188,8 @@ def main():
                        "rays_per_step_per_gpu": args.rays, "fine_samples_per_ray": k_mean / args.rays,
                        "parallelism": f"dp{world} (cameras sharded, 1 flat all-reduce/step)"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC, profiles/r01b_pmc_traffic.json)",
                          "kernel_ms": kern_ms,
                          "step_algorithmic_tflops": 3 * (F_FINE * k_mean + F_COARSE * args.rays * 64) / 1e12},
         }

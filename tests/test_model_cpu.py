@@ -1,0 +1,106 @@
+"""Host-side contract of the reference-shaped classes that needs no GPU: constructor keys, parameter names /
+shapes (checkpoint compatibility), flat-buffer aliasing, loss and RAdam arithmetic."""
+import math
+
+import pytest
+import torch
+
+from mc_nerf_amd import synthetic as S
+
+
+def test_state_dict_keys_match_reference_checkpoint_format():
+    from mc_nerf_amd.model import MC_Model
+    sp = S.make_sys_param("cpu", samples=64, scale=2, batch=128, H=8, W=8)
+    m = MC_Model(sp)
+    keys = list(m.state_dict().keys())
+    expect = ["weights_pose", "weights_pose_intr", "weights_ux", "weights_uy", "weights_fx", "weights_fy"]
+    for net, depth in (("nerf_coarse", 4), ("nerf_fine", 8)):
+        for i in range(1, depth + 1):
+            expect += [f"nerf.{net}.xyz_encoding_{i}.0.weight", f"nerf.{net}.xyz_encoding_{i}.0.bias"]
+        for head in ("sigma", "sh"):
+            expect += [f"nerf.{net}.{head}.0.weight", f"nerf.{net}.{head}.0.bias",
+                       f"nerf.{net}.{head}.2.weight", f"nerf.{net}.{head}.2.bias"]
+    assert keys == expect and len(keys) == 46
+    sd = m.state_dict()
+    assert sd["nerf.nerf_fine.xyz_encoding_5.0.weight"].shape == (256, 319)       # skip layer: [x_enc, h]
+    assert sd["nerf.nerf_coarse.xyz_encoding_3.0.weight"].shape == (128, 191)
+    assert sd["nerf.nerf_fine.sh.2.weight"].shape == (27, 256) and sd["weights_pose"].shape == (110, 6)
+    n_coarse = sum(p.numel() for p in m.nerf.nerf_coarse.parameters())
+    n_fine = sum(p.numel() for p in m.nerf.nerf_fine.parameters())
+    assert (n_coarse, n_fine) == (102428, 631836)
+    # main.py:182-186 groups parameters by the first dotted component
+    assert {k.split(".")[0] for k, _ in m.named_parameters() if "." in k} == {"nerf"}
+
+
+def test_parameters_alias_the_flat_buffer_and_survive_load_and_to():
+    from mc_nerf_amd.model import NeRF_Model
+    from oracle import mcnerf_oracle as O
+    sp = S.make_sys_param("cpu", samples=32, scale=2, batch=16, H=8, W=8, coarse=(4, 32, [2]), fine=(8, 64, [4]))
+    m = NeRF_Model(sp)
+    net = m.nerf_coarse
+    flat = net.flat_params()
+    p = net.xyz_encoding_2[0].bias
+    with torch.no_grad():
+        p.add_(1.0)                                   # an optimiser-style in-place update ...
+    off = net._offsets[3]
+    assert torch.equal(flat[off:off + p.numel()], p.detach())       # ... is visible in the flat buffer
+    ref = O.init_params(O.NetCfg(4, 32, (2,)), 5)
+    net.load_state_dict(ref)                          # load_state_dict copies in place: aliasing preserved
+    assert net.flat_params().data_ptr() == flat.data_ptr()
+    assert torch.equal(flat[off:off + p.numel()], ref["xyz_encoding_2.0.bias"])
+    net.double().float()                              # .to()/dtype round trip re-creates storages: re-flattened lazily
+    flat2 = net.flat_params()
+    assert net._aliased() and torch.equal(flat2[off:off + p.numel()], ref["xyz_encoding_2.0.bias"])
+
+
+def test_loss_matches_reference_formula():
+    from mc_nerf_amd.model import MC_NeRF_Loss
+    g = torch.Generator().manual_seed(0)
+    a, b, gt = (torch.rand(50, 3, generator=g) for _ in range(3))
+    L = MC_NeRF_Loss(dict(data_img_h=600, data_img_w=800))
+    assert torch.allclose(L.get_rgb_loss([a, b, gt]), ((a - gt) ** 2).mean() + ((b - gt) ** 2).mean())
+    assert torch.allclose(L.get_rgb_loss([a, None, gt]), ((a - gt) ** 2).mean())
+    pd, pg = torch.rand(1, 4, 5, 2, generator=g) * 800, torch.rand(1, 4, 5, 2, generator=g) * 800
+    lr = ((pd[..., 0] - pg[..., 0]) / 800).pow(2).mean() + ((pd[..., 1] - pg[..., 1]) / 600).pow(2).mean()
+    assert torch.allclose(L.get_reproject_loss([pd, pg]), lr, rtol=1e-5)
+    tot = L({"intr": [pd, pg], "rgb": [a, b, gt]}, "GLOBAL_OPTIM_EPOCH")          # intr term rescaled to 1
+    assert torch.allclose(tot, lr / (lr + 1e-8) + L.get_rgb_loss([a, b, gt]))
+
+
+def test_radam_follows_reference_update_rule():
+    """Replays model/net_utils.py:62-99 in float64 python for one scalar parameter."""
+    from mc_nerf_amd.model import RAdam
+    p = torch.nn.Parameter(torch.tensor([0.7]))
+    opt = RAdam([p], lr=0.05, betas=(0.9, 0.999), weight_decay=0.01)
+    x, m, v = 0.7, 0.0, 0.0
+    for step in range(1, 13):
+        g = math.sin(step) + 0.3 * x
+        p.grad = torch.tensor([g], dtype=torch.float32)
+        opt.step()
+        v = 0.999 * v + 0.001 * g * g
+        m = 0.9 * m + 0.1 * g
+        b2t = 0.999 ** step
+        n_max = 2 / (1 - 0.999) - 1
+        n_sma = n_max - 2 * step * b2t / (1 - b2t)
+        x += -0.01 * 0.05 * x
+        if n_sma >= 5:
+            ss = math.sqrt((1 - b2t) * (n_sma - 4) / (n_max - 4) * (n_sma - 2) / n_sma * n_max / (n_max - 2)) / (1 - 0.9 ** step)
+            x += -ss * 0.05 * m / (math.sqrt(v) + 1e-8)
+        else:
+            x += -0.05 * m / (1 - 0.9 ** step)
+        assert abs(float(p) - x) < 2e-5, (step, float(p), x)
+
+
+def test_barf_weights_and_host_settings():
+    from mc_nerf_amd.model import NeRF_Model
+    from oracle import mcnerf_oracle as O
+    sp = S.make_sys_param("cpu", samples=64, scale=2, batch=16, H=8, W=8, barf_mask=True)
+    m = NeRF_Model(sp)
+    cfg = O.RenderCfg(barf_mode=True, barf_start=sp["barf_start"], barf_end=sp["barf_end"])
+    for r in (0.1, 0.45, 0.6, 0.9):
+        assert torch.equal(m.emmbedding_xyz.barf_weights(r), O.barf_weights(r, cfg))
+    m.emmbedding_xyz.barf_mode = False
+    assert torch.equal(m.emmbedding_xyz.barf_weights(0.5), torch.ones(10))
+    assert torch.equal(m.z_vals_f, torch.linspace(1.0, 8.0, 128)) and m.settings.samples_f == 128
+    with pytest.raises(Exception):
+        m(torch.zeros(4, 3), torch.zeros(4, 3), 0, 1.0)          # CPU tensors: fails loudly, no fallback

@@ -142,3 +142,81 @@ def test_params_survive_optimizer_and_state_dict(gpu_device):
     m.nerf_fine.load_state_dict(pf)
     rgb_c3, _ = m.render_rays_train(d, o, 0, 1.0, **kw)
     assert err(rgb_c3, g["rgb_c"]) < TOL
+
+
+def test_mc_model_joint_optimisation_step_matches_oracle(gpu_device, monkeypatch):
+    """One GLOBAL_OPTIM training step of MC_Model (camera parametrisation -> ray-gen kernel -> render ->
+    loss -> backward through the ray-gen kernel into the camera parameters) against the same computation
+    composed from the CPU oracle."""
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd.model import MC_Model, MC_NeRF_Loss
+    import mc_nerf_amd.model.mc_nerf as mm
+    dev = gpu_device
+    H, W, B, cam = 24, 32, 96, 7
+    sp = S.make_sys_param(dev, samples=32, scale=2, batch=B, H=H, W=W, coarse=(4, 32, [2]), fine=(8, 64, [4]),
+                          barf_start=0.2, barf_end=0.9)
+    torch.manual_seed(3)
+    model = MC_Model(sp).to(dev)
+    S.init_cameras_near_gt(model, noise=0.02, seed=1)
+    C = model.train_numb
+    g = torch.Generator().manual_seed(11)
+    idx = torch.randperm(H * W, generator=g)[:B]
+    draws = dict(jitter=torch.rand(B, 1, generator=g) * 7.0 / 32, eps_c=torch.randn(B, 32, generator=g),
+                 eps_sel=torch.randn(B, 32, generator=g), eps_f=torch.randn(B, 64, generator=g))
+    monkeypatch.setattr(mm.torch, "randperm", lambda n, device=None: idx.to(device) if n == H * W else None)
+    orig = model.nerf.render_rays_train
+    model.nerf.render_rays_train = lambda d, o, e, r, only_coarse=False: orig(
+        d, o, e, r, only_coarse, **{k: v.to(dev) for k, v in draws.items()})
+    wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0], seed=2)
+    gt_img = torch.rand(1, H * W, 3, generator=g)
+    data = (gt_img, torch.tensor([cam]), wpts, pts, wpts, pts)
+    cur_ratio = 0.6
+    loss_dict, intr_show, pose_show, rays_valid = model(data, 20, "GLOBAL_OPTIM_EPOCH", cur_ratio)
+    assert rays_valid[0].shape == (H * W, 3) and intr_show[1].shape == (C, 3, 3) and model.opt_idx == 1
+    loss = MC_NeRF_Loss(sp)(loss_dict, "GLOBAL_OPTIM_EPOCH")
+    loss.backward()
+
+    # ---- the same step from the oracle
+    cfg = O.RenderCfg(samples=32, scale=2, coarse=O.NetCfg(4, 32, (2,)), fine=O.NetCfg(8, 64, (4,)), barf_mode=True,
+                      barf_start=0.2, barf_end=0.9)
+    cp = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in model.named_parameters()}
+    pc = {k[len("nerf.nerf_coarse."):]: v for k, v in cp.items() if k.startswith("nerf.nerf_coarse.")}
+    pf = {k[len("nerf.nerf_fine."):]: v for k, v in cp.items() if k.startswith("nerf.nerf_fine.")}
+    K = O.intrinsics_from_weights(H, W, cp["weights_fx"], cp["weights_fy"], cp["weights_ux"], cp["weights_uy"])
+    pose = O.se3_to_SE3(cp["weights_pose"])
+    calib = O.se3_to_SE3(cp["weights_pose_intr"])
+    camp = torch.cat([wpts, torch.ones_like(wpts[..., :1])], -1) @ calib.unsqueeze(0).transpose(-2, -1)
+    pix = camp @ K.unsqueeze(0).transpose(-2, -1)
+    rep = pix[..., :2] / pix[..., 2:]
+    l_intr = ((rep[..., 0] - pts[..., 0]) / W).pow(2).mean() + ((rep[..., 1] - pts[..., 1]) / H).pow(2).mean()
+    d, o = O.get_rays_at(pose[cam], torch.linalg.inv(K[cam]), idx, W)
+    r = O.render_rays_train(pc, pf, cfg, d, o, cur_ratio, draws["jitter"], draws["eps_c"], draws["eps_sel"], draws["eps_f"])
+    ref_loss = l_intr / (l_intr.detach() + 1e-8) + O.rgb_loss(r["rgb_c"], r["rgb_f"], gt_img.reshape(-1, 3)[idx])
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-5
+    assert err(loss_dict["rgb"][0], r["rgb_c"].detach()) < TOL and err(loss_dict["rgb"][1], r["rgb_f"].detach()) < TOL
+    for n, p in model.named_parameters():
+        ref_g = cp[n].grad
+        if ref_g is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        scale = max(1.0, float(ref_g.abs().max()))
+        assert err(p.grad, ref_g.numpy()) < 2e-4 * scale, (n, err(p.grad, ref_g.numpy()), scale)
+    # the rgb loss reaches only the rendered camera's pose row (SURVEY.md 8c probe)
+    gp = model.weights_pose.grad
+    assert float(gp[cam].abs().max()) > 0 and float(gp[torch.arange(C) != cam].abs().max()) == 0.0
+
+
+def test_mc_model_demo_call(gpu_device):
+    """model(img_idx) in demo mode: chunked render of a whole image, CPU tensors out (model/mc_nerf.py:106-122)."""
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd.model import MC_Model
+    dev = gpu_device
+    sp = S.make_sys_param(dev, samples=32, scale=2, batch=200, H=20, W=24, coarse=(4, 32, [2]), fine=(8, 64, [4]))
+    torch.manual_seed(0)
+    model = MC_Model(sp).to(dev)
+    model.sys_param["mode"] = 1
+    model.nerf.mode = 1
+    rgb, depth, opacity = model(torch.tensor([5]))
+    assert rgb.shape == (480, 3) and depth.shape == (480, 1) and opacity.shape == (480, 1)
+    assert rgb.device.type == "cpu" and bool(torch.isfinite(rgb).all()) and float(opacity.min()) >= 0.0
