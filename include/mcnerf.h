@@ -121,6 +121,14 @@ int mcnerf_select_fine(const float* w_sel, const uint32_t* wmax_bits, float thre
 /* The random cap of model/mc_nerf.py:630-632: idx_out[i] = idx_in[perm[i]], i < keep; *count = keep. */
 int mcnerf_cap_gather(const int32_t* idx_in, const int64_t* perm, int keep, int32_t* idx_out, int32_t* count, void* stream);
 
+/* Fused multi-tensor Rectified-Adam step (one launch for all tensors of a param group).
+ * Replaces the per-tensor loop of RAdam.step (model/net_utils.py:38-99).  The arrays of n_tensors device
+ * pointers / sizes live on the HOST; step_size and `rectified` (N_sma >= 5) are the host-side scalars of the
+ * reference's step-size cache (model/net_utils.py:67-86) for the tensors' common step count. */
+int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const long long* sizes, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, float step_size, int rectified, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

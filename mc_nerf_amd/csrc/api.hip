@@ -150,4 +150,27 @@ int mcnerf_cap_gather(const int32_t* idx_in, const int64_t* perm, int keep, int3
     return check("mcnerf_cap_gather", mcn_launch_cap_gather((const int2*)idx_in, (const long long*)perm, keep, (int2*)idx_out, count, (hipStream_t)stream));
 }
 
+int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const long long* sizes, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, float step_size, int rectified, void* stream) {
+    REQ(n_tensors >= 0 && params && grads && exp_avg && exp_avg_sq && sizes, "mcnerf_radam_step");
+    for (int t0 = 0; t0 < n_tensors; t0 += MCN_RADAM_MAXT) {           // 64 tensors per launch
+        McnRadamTable t;
+        t.n_tensors = n_tensors - t0 < MCN_RADAM_MAXT ? n_tensors - t0 : MCN_RADAM_MAXT;
+        t.rectified = rectified; t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.wd = weight_decay;
+        t.step_size = step_size;
+        int blocks = 0;
+        for (int i = 0; i < t.n_tensors; ++i) {
+            REQ(params[t0 + i] && grads[t0 + i] && exp_avg[t0 + i] && exp_avg_sq[t0 + i] && sizes[t0 + i] >= 0, "mcnerf_radam_step");
+            t.p[i] = params[t0 + i]; t.g[i] = grads[t0 + i]; t.m[i] = exp_avg[t0 + i]; t.v[i] = exp_avg_sq[t0 + i];
+            t.n[i] = sizes[t0 + i];
+            t.first_block[i] = blocks;
+            blocks += (int)((sizes[t0 + i] + MCN_RADAM_CHUNK - 1) / MCN_RADAM_CHUNK);
+        }
+        const int rc = check("mcnerf_radam_step", mcn_launch_radam(t, blocks, (hipStream_t)stream));
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 }  // extern "C"

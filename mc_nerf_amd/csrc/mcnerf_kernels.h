@@ -130,3 +130,19 @@ struct McnRaygenBwdArgs {
     float* d_kinv;            // [9]
 };
 hipError_t mcn_launch_raygen_bwd(const McnRaygenBwdArgs& a, hipStream_t st);
+
+// ---- fused multi-tensor RAdam (optim.hip)
+#define MCN_RADAM_MAXT 64
+#define MCN_RADAM_CHUNK 4096
+struct McnRadamTable {
+    int n_tensors;
+    int rectified;            // N_sma >= 5
+    float lr, beta1, beta2, eps, wd, step_size;
+    float* p[MCN_RADAM_MAXT];
+    const float* g[MCN_RADAM_MAXT];
+    float* m[MCN_RADAM_MAXT];
+    float* v[MCN_RADAM_MAXT];
+    long long n[MCN_RADAM_MAXT];
+    int first_block[MCN_RADAM_MAXT];
+};
+hipError_t mcn_launch_radam(const McnRadamTable& t, int n_blocks, hipStream_t st);

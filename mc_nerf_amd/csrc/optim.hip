@@ -1,0 +1,44 @@
+// Fused multi-tensor Rectified-Adam step for gfx950: ONE launch updates every parameter tensor of a
+// param group (46 MLP tensors + 6 camera tensors in MC-NeRF), replacing the reference's per-tensor Python
+// loop of ~10 ATen ops each (model/net_utils.py:38-99).  Pure streaming: 16 B/element read + 12 B written.
+//
+// Semantics per element (reference :62-63, 88-99), with the scalar step size / N_sma computed on the host
+// exactly like the reference's 10-slot cache (:67-86):
+//   v = beta2 v + (1-beta2) g^2 ;  m = beta1 m + (1-beta1) g
+//   rectified (N_sma >= 5):  p -= wd*lr*p ;  p -= step_size*lr * m / (sqrt(v) + eps)
+//   otherwise (step_size>0): p -= wd*lr*p ;  p -= step_size*lr * m
+#include "mcnerf_kernels.h"
+
+__global__ __launch_bounds__(256) void radam_kernel(McnRadamTable t) {
+    // block -> (tensor, chunk): blocks are dealt to tensors by their precomputed first-block index
+    int ti = 0;
+    while (ti + 1 < t.n_tensors && (int)blockIdx.x >= t.first_block[ti + 1]) ++ti;
+    const long long base = (long long)((int)blockIdx.x - t.first_block[ti]) * MCN_RADAM_CHUNK;
+    float* __restrict__ p = t.p[ti];
+    const float* __restrict__ g = t.g[ti];
+    float* __restrict__ m = t.m[ti];
+    float* __restrict__ v = t.v[ti];
+    const long long n = t.n[ti];
+    const float b1 = t.beta1, b2 = t.beta2, decay = t.wd * t.lr, ss = t.step_size * t.lr;
+    for (long long i = base + threadIdx.x; i < base + MCN_RADAM_CHUNK && i < n; i += 256) {
+        const float gi = g[i];
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        v[i] = vi; m[i] = mi;
+        float pi = p[i];
+        if (t.rectified) {
+            pi += -decay * pi;
+            pi += -ss * (mi / (sqrtf(vi) + t.eps));
+        } else if (t.step_size > 0.f) {
+            pi += -decay * pi;
+            pi += -ss * mi;
+        }
+        p[i] = pi;
+    }
+}
+
+hipError_t mcn_launch_radam(const McnRadamTable& t, int n_blocks, hipStream_t st) {
+    if (n_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(radam_kernel, dim3(n_blocks), dim3(256), 0, st, t);
+    return hipGetLastError();
+}

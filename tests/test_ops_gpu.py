@@ -241,3 +241,28 @@ def test_raygen(gpu_device):
     d_pose, d_kinv = ops.raygen_bwd(pose.detach().to(dev), kinv.detach().to(dev), pix.to(dev), W, gd.to(dev), go.to(dev))
     assert maxerr(d_pose, pose.grad) < 1e-4 * max(1.0, float(pose.grad.abs().max()))
     assert maxerr(d_kinv, kinv.grad) < 1e-4 * max(1.0, float(kinv.grad.abs().max()))
+
+
+def test_fused_radam_matches_host_arithmetic(gpu_device):
+    """mcnerf_radam_step (one launch, many tensors) against the per-tensor torch implementation of the same
+    update rule, through the SGD-like warm-up (N_sma < 5) and the rectified regime, with weight decay."""
+    from mc_nerf_amd.model import RAdam
+    dev = gpu_device
+    g = torch.Generator().manual_seed(0)
+    shapes = [(256, 319), (256,), (1, 256), (1,), (27, 256), (110, 6), (5000,)]
+    cpu = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    gpu = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in cpu]
+    oc = RAdam(cpu, lr=3e-3, weight_decay=4e-4)
+    og = RAdam(gpu, lr=3e-3, weight_decay=4e-4)
+    for step in range(9):
+        for pc, pg in zip(cpu, gpu):
+            gr = torch.randn(pc.shape, generator=g)
+            pc.grad, pg.grad = gr, gr.to(dev)
+        if step == 4:                      # a tensor without a gradient keeps its own step count
+            cpu[2].grad = None
+            gpu[2].grad = None
+        oc.step()
+        og.step()
+    for pc, pg in zip(cpu, gpu):
+        assert maxerr(pg, pc) < 1e-6
+    assert og.state[gpu[2]]["step"] == 8 and og.state[gpu[0]]["step"] == 9
