@@ -121,6 +121,20 @@ int mcnerf_select_fine(const float* w_sel, const uint32_t* wmax_bits, float thre
 /* The random cap of model/mc_nerf.py:630-632: idx_out[i] = idx_in[perm[i]], i < keep; *count = keep. */
 int mcnerf_cap_gather(const int32_t* idx_in, const int64_t* perm, int keep, int32_t* idx_out, int32_t* count, void* stream);
 
+/* Fused camera parametrisation of all C cameras.
+ * Replaces add_weights2intr / add_weights2pose / add_weights2calib_pose / se3_to_SE3 / taylor_A,B,C /
+ * inverse_intrinsic (model/mc_nerf.py:171-210, 269-316):
+ *   K [C,3,3] = [[|W wfx|,0,|W/2 wux|],[0,|W wfy|,|H/2 wuy|],[0,0,1]], Kinv its analytic inverse,
+ *   pose / calib [C,3,4] = se3_to_SE3(wpose / wpose_intr) with the reference's 11-term Taylor series. */
+int mcnerf_camera_fwd(const float* wpose, const float* wpose_intr, const float* wfx, const float* wfy, const float* wux,
+                      const float* wuy, int C, int H, int W, float* K, float* Kinv, float* pose, float* calib, void* stream);
+/* Backward of the above: upstream dK / dKinv [C,3,3], dpose / dcalib [C,3,4] (any may be NULL) ->
+ * gradients of the six parameter tensors (WRITTEN, not accumulated). */
+int mcnerf_camera_bwd(const float* wpose, const float* wpose_intr, const float* wfx, const float* wfy, const float* wux,
+                      const float* wuy, int C, int H, int W, const float* dK, const float* dKinv, const float* dpose,
+                      const float* dcalib, float* d_wpose, float* d_wpose_intr, float* d_wfx, float* d_wfy, float* d_wux,
+                      float* d_wuy, void* stream);
+
 /* Fused multi-tensor Rectified-Adam step (one launch for all tensors of a param group).
  * Replaces the per-tensor loop of RAdam.step (model/net_utils.py:38-99).  The arrays of n_tensors device
  * pointers / sizes live on the HOST; step_size and `rectified` (N_sma >= 5) are the host-side scalars of the

@@ -150,6 +150,23 @@ int mcnerf_cap_gather(const int32_t* idx_in, const int64_t* perm, int keep, int3
     return check("mcnerf_cap_gather", mcn_launch_cap_gather((const int2*)idx_in, (const long long*)perm, keep, (int2*)idx_out, count, (hipStream_t)stream));
 }
 
+int mcnerf_camera_fwd(const float* wpose, const float* wpose_intr, const float* wfx, const float* wfy, const float* wux,
+                      const float* wuy, int C, int H, int W, float* K, float* Kinv, float* pose, float* calib, void* stream) {
+    REQ(wpose && wpose_intr && wfx && wfy && wux && wuy && K && Kinv && pose && calib && C >= 0 && H > 0 && W > 0, "mcnerf_camera_fwd");
+    McnCameraArgs a = {wpose, wpose_intr, wfx, wfy, wux, wuy, C, H, W, K, Kinv, pose, calib};
+    return check("mcnerf_camera_fwd", mcn_launch_camera_fwd(a, (hipStream_t)stream));
+}
+int mcnerf_camera_bwd(const float* wpose, const float* wpose_intr, const float* wfx, const float* wfy, const float* wux,
+                      const float* wuy, int C, int H, int W, const float* dK, const float* dKinv, const float* dpose,
+                      const float* dcalib, float* d_wpose, float* d_wpose_intr, float* d_wfx, float* d_wfy, float* d_wux,
+                      float* d_wuy, void* stream) {
+    REQ(wpose && wpose_intr && wfx && wfy && wux && wuy && C >= 0 && H > 0 && W > 0, "mcnerf_camera_bwd");
+    REQ(d_wpose && d_wpose_intr && d_wfx && d_wfy && d_wux && d_wuy, "mcnerf_camera_bwd");
+    McnCameraArgs a = {wpose, wpose_intr, wfx, wfy, wux, wuy, C, H, W, nullptr, nullptr, nullptr, nullptr};
+    McnCameraGrads g = {dK, dKinv, dpose, dcalib, d_wpose, d_wpose_intr, d_wfx, d_wfy, d_wux, d_wuy};
+    return check("mcnerf_camera_bwd", mcn_launch_camera_bwd(a, g, (hipStream_t)stream));
+}
+
 int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const long long* sizes, float lr, float beta1, float beta2, float eps,
                       float weight_decay, float step_size, int rectified, void* stream) {

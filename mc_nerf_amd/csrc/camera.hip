@@ -1,0 +1,168 @@
+// Fused camera parametrisation for gfx950: learnable multipliers -> K, K^-1 and
+// se(3) -> SE(3) for BOTH pose sets of every camera, forward and backward, one thread per camera.
+//
+// Replaces MC_Model.add_weights2intr / add_weights2pose / add_weights2calib_pose / se3_to_SE3 /
+// taylor_A,B,C / inverse_intrinsic (model/mc_nerf.py:171-210, 269-316): ~1500 ATen dispatches per step
+// in the reference (a Python loop of per-matrix inverses among them), two launches here.
+//   K = [[|W wfx|, 0, |W/2 wux|], [0, |W wfy|, |H/2 wuy|], [0,0,1]]   (the reference scales fy by W too, :172-173)
+//   K^-1 analytic;  [R|t] = [I + A wx + B wx^2 | (I + B wx + C wx^2) u],  A,B,C = 11-term Taylor series in theta^2
+#include "mcnerf_kernels.h"
+
+#define CAM_NTH 10
+
+struct Series { float A, B, C, dA, dB, dC; };     // values and derivatives wrt s = theta^2
+
+__device__ __forceinline__ Series taylor_abc(float s) {
+    Series r = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dA = 1.f, dB = 1.f, dC = 1.f;            // running denominators (reference :294-315)
+    float pw = 1.f, pw_prev = 0.f;                 // s^i and s^(i-1)
+    float sign = 1.f;
+    for (int i = 0; i <= CAM_NTH; ++i) {
+        if (i > 0) dA *= (float)((2 * i) * (2 * i + 1));
+        dB *= (float)((2 * i + 1) * (2 * i + 2));
+        dC *= (float)((2 * i + 2) * (2 * i + 3));
+        r.A += sign * pw / dA; r.B += sign * pw / dB; r.C += sign * pw / dC;
+        r.dA += sign * (float)i * pw_prev / dA; r.dB += sign * (float)i * pw_prev / dB; r.dC += sign * (float)i * pw_prev / dC;
+        pw_prev = pw; pw *= s; sign = -sign;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void skew(const float* w, float (&wx)[3][3]) {
+    wx[0][0] = 0.f;   wx[0][1] = -w[2]; wx[0][2] = w[1];
+    wx[1][0] = w[2];  wx[1][1] = 0.f;   wx[1][2] = -w[0];
+    wx[2][0] = -w[1]; wx[2][1] = w[0];  wx[2][2] = 0.f;
+}
+
+__device__ void se3_fwd(const float* wu, float* Rt /*[3][4]*/) {
+    float wx[3][3], wx2[3][3];
+    skew(wu, wx);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wx2[i][j] = wx[i][0] * wx[0][j] + wx[i][1] * wx[1][j] + wx[i][2] * wx[2][j];
+    const Series t = taylor_abc(wu[0] * wu[0] + wu[1] * wu[1] + wu[2] * wu[2]);
+    const float* u = wu + 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float tv = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float id = i == j ? 1.f : 0.f;
+            Rt[i * 4 + j] = id + t.A * wx[i][j] + t.B * wx2[i][j];
+            tv += (id + t.B * wx[i][j] + t.C * wx2[i][j]) * u[j];
+        }
+        Rt[i * 4 + 3] = tv;
+    }
+}
+
+// gradient of se3_fwd: g = d loss / d Rt [3][4]  ->  d loss / d wu [6] (accumulated into dwu)
+__device__ void se3_bwd(const float* wu, const float* g, float* dwu) {
+    float wx[3][3], wx2[3][3];
+    skew(wu, wx);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wx2[i][j] = wx[i][0] * wx[0][j] + wx[i][1] * wx[1][j] + wx[i][2] * wx[2][j];
+    const Series t = taylor_abc(wu[0] * wu[0] + wu[1] * wu[1] + wu[2] * wu[2]);
+    const float* u = wu + 3;
+    float gt[3] = {g[3], g[7], g[11]};
+    float wxu[3], wx2u[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        wxu[i] = wx[i][0] * u[0] + wx[i][1] * u[1] + wx[i][2] * u[2];
+        wx2u[i] = wx2[i][0] * u[0] + wx2[i][1] * u[1] + wx2[i][2] * u[2];
+    }
+    float dA = 0.f, dB = 0.f, dC = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { dA += g[i * 4 + j] * wx[i][j]; dB += g[i * 4 + j] * wx2[i][j]; }
+        dB += gt[i] * wxu[i];
+        dC += gt[i] * wx2u[i];
+    }
+    // d wx: from R = I + A wx + B wx wx and t = u + B wx u + C wx wx u
+    float dwx[3][3];
+    float wTgt[3];      // wx^T gt
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wTgt[i] = wx[0][i] * gt[0] + wx[1][i] * gt[1] + wx[2][i] * gt[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float gw = 0.f, wg = 0.f;       // (G wx^T)[i][j], (wx^T G)[i][j]
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { gw += g[i * 4 + k] * wx[j][k]; wg += wx[k][i] * g[k * 4 + j]; }
+            dwx[i][j] = t.A * g[i * 4 + j] + t.B * (gw + wg) + t.B * gt[i] * u[j] + t.C * (gt[i] * wxu[j] + wTgt[i] * u[j]);
+        }
+    const float ds = dA * t.dA + dB * t.dB + dC * t.dC;       // through s = |w|^2
+    dwu[0] += (dwx[2][1] - dwx[1][2]) + 2.f * wu[0] * ds;
+    dwu[1] += (dwx[0][2] - dwx[2][0]) + 2.f * wu[1] * ds;
+    dwu[2] += (dwx[1][0] - dwx[0][1]) + 2.f * wu[2] * ds;
+    // d u = (I + B wx + C wx^2)^T gt
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float v = gt[j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v += (t.B * wx[i][j] + t.C * wx2[i][j]) * gt[i];
+        dwu[3 + j] += v;
+    }
+}
+
+__global__ void camera_fwd_kernel(McnCameraArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    const float Wf = (float)a.W, Hf = (float)a.H;
+    const float fx = fabsf(Wf * a.wfx[c]), fy = fabsf(Wf * a.wfy[c]);
+    const float ux = fabsf(Wf / 2.f * a.wux[c]), uy = fabsf(Hf / 2.f * a.wuy[c]);
+    float* K = a.K + c * 9;
+    K[0] = fx; K[1] = 0.f; K[2] = ux; K[3] = 0.f; K[4] = fy; K[5] = uy; K[6] = 0.f; K[7] = 0.f; K[8] = 1.f;
+    float* Ki = a.Kinv + c * 9;
+    Ki[0] = 1.f / fx; Ki[1] = 0.f; Ki[2] = -ux / fx; Ki[3] = 0.f; Ki[4] = 1.f / fy; Ki[5] = -uy / fy;
+    Ki[6] = 0.f; Ki[7] = 0.f; Ki[8] = 1.f;
+    se3_fwd(a.wpose + c * 6, a.pose + c * 12);
+    se3_fwd(a.wpose_intr + c * 6, a.calib + c * 12);
+}
+
+__global__ void camera_bwd_kernel(McnCameraArgs a, McnCameraGrads g) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    const float Wf = (float)a.W, Hf = (float)a.H;
+    const float rfx = Wf * a.wfx[c], rfy = Wf * a.wfy[c], rux = Wf / 2.f * a.wux[c], ruy = Hf / 2.f * a.wuy[c];
+    const float fx = fabsf(rfx), fy = fabsf(rfy), ux = fabsf(rux), uy = fabsf(ruy);
+    const float* dK = g.dK ? g.dK + c * 9 : nullptr;
+    const float* dKi = g.dKinv ? g.dKinv + c * 9 : nullptr;
+    float dfx = 0.f, dfy = 0.f, dux = 0.f, duy = 0.f;
+    if (dK) { dfx += dK[0]; dux += dK[2]; dfy += dK[4]; duy += dK[5]; }
+    if (dKi) {
+        dfx += -dKi[0] / (fx * fx) + dKi[2] * ux / (fx * fx);
+        dux += -dKi[2] / fx;
+        dfy += -dKi[4] / (fy * fy) + dKi[5] * uy / (fy * fy);
+        duy += -dKi[5] / fy;
+    }
+    // |x| has sign(x) as its derivative (0 at 0, like torch.abs)
+    g.d_wfx[c] = dfx * (rfx > 0.f ? 1.f : (rfx < 0.f ? -1.f : 0.f)) * Wf;
+    g.d_wfy[c] = dfy * (rfy > 0.f ? 1.f : (rfy < 0.f ? -1.f : 0.f)) * Wf;
+    g.d_wux[c] = dux * (rux > 0.f ? 1.f : (rux < 0.f ? -1.f : 0.f)) * Wf / 2.f;
+    g.d_wuy[c] = duy * (ruy > 0.f ? 1.f : (ruy < 0.f ? -1.f : 0.f)) * Hf / 2.f;
+    float dw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g.dpose) se3_bwd(a.wpose + c * 6, g.dpose + c * 12, dw);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g.d_wpose[c * 6 + k] = dw[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dw[k] = 0.f;
+    if (g.dcalib) se3_bwd(a.wpose_intr + c * 6, g.dcalib + c * 12, dw);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g.d_wpose_intr[c * 6 + k] = dw[k];
+}
+
+hipError_t mcn_launch_camera_fwd(const McnCameraArgs& a, hipStream_t st) {
+    if (a.C <= 0) return hipSuccess;
+    hipLaunchKernelGGL(camera_fwd_kernel, dim3((a.C + 63) / 64), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t mcn_launch_camera_bwd(const McnCameraArgs& a, const McnCameraGrads& g, hipStream_t st) {
+    if (a.C <= 0) return hipSuccess;
+    hipLaunchKernelGGL(camera_bwd_kernel, dim3((a.C + 63) / 64), dim3(64), 0, st, a, g);
+    return hipGetLastError();
+}

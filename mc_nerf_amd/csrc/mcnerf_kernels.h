@@ -146,3 +146,21 @@ struct McnRadamTable {
     int first_block[MCN_RADAM_MAXT];
 };
 hipError_t mcn_launch_radam(const McnRadamTable& t, int n_blocks, hipStream_t st);
+
+// ---- fused camera parametrisation (camera.hip)
+struct McnCameraArgs {
+    const float* wpose;       // [C,6] se(3) of the world->cam poses
+    const float* wpose_intr;  // [C,6] se(3) of the calibration poses
+    const float* wfx; const float* wfy; const float* wux; const float* wuy;   // [C]
+    int C, H, W;
+    float* K;                 // [C,3,3]
+    float* Kinv;              // [C,3,3]
+    float* pose;              // [C,3,4]
+    float* calib;             // [C,3,4]
+};
+struct McnCameraGrads {
+    const float* dK; const float* dKinv; const float* dpose; const float* dcalib;     // upstream (any may be null)
+    float* d_wpose; float* d_wpose_intr; float* d_wfx; float* d_wfy; float* d_wux; float* d_wuy;   // written
+};
+hipError_t mcn_launch_camera_fwd(const McnCameraArgs& a, hipStream_t st);
+hipError_t mcn_launch_camera_bwd(const McnCameraArgs& a, const McnCameraGrads& g, hipStream_t st);

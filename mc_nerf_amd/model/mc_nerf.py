@@ -22,7 +22,7 @@ import torch.distributed as dist
 
 from .. import ops
 from .net_block import CorseFine_NeRF, SinCosEmbedding
-from .render import RaygenFn, RenderSettings, RenderTrainFn, render_test
+from .render import CameraFn, RaygenFn, RenderSettings, RenderTrainFn, render_test
 
 
 def _rank():
@@ -209,6 +209,7 @@ class MC_Model(nn.Module):
         self.register_parameters()
         self.nerf = NeRF_Model(sys_param).to(self.device)
         self.count_rays = 0
+        self.intr_inv_adj = None
         self.opt_idx = 0
         self.last_epoch_type = 0
 
@@ -241,7 +242,8 @@ class MC_Model(nn.Module):
             emb.barf_mode = joint                                   # :74 / :86
             self.intr_adj, self.pose_adj, self.calib_pose_adj = self.add_weights2param(True, joint, True)
             loss_dict["intr"] = [self.get_reproject_pixels(intr_wpts, self.intr_adj, self.calib_pose_adj), intr_pts]
-            kinv = self.inverse_intrinsic(self.intr_adj[cam:cam + 1])[0]
+            kinv = self.intr_inv_adj[cam] if self.intr_inv_adj is not None else \
+                self.inverse_intrinsic(self.intr_adj[cam:cam + 1])[0]
             # pixel subset first (same device randperm as :329), rays only for those pixels
             rand_idx = torch.randperm(self.img_h * self.img_w, device=self.device)[: self.batch]
             rays_d, rays_o = RaygenFn.apply(self.pose_adj[cam], kinv, rand_idx, self.img_w)
@@ -284,8 +286,19 @@ class MC_Model(nn.Module):
         return rays_d[idx], rays_o[idx], idx
 
     # ------------------------------------------------------------------ camera parametrisation (:155-210, 269-316)
-    # Stock PyTorch for now (a fused kernel for this branch is the next widening step).
+    # On the GPU all six parameter tensors go through ONE fused kernel each way (CameraFn, csrc/camera.hip;
+    # SURVEY.md 8f row f1).  The per-piece torch methods below restate the same maths; they serve host tensors
+    # (the CPU plumbing tests of the camera-only stage) and API compatibility.
     def add_weights2param(self, intr=True, extr=True, calib_extr=False):
+        self.intr_inv_adj = None
+        if self.weights_pose.is_cuda:
+            det = lambda t, on: t if on else t.detach()
+            K, Kinv, pose, calib = CameraFn.apply(det(self.weights_pose, extr), det(self.weights_pose_intr, calib_extr),
+                                                  det(self.weights_fx, intr), det(self.weights_fy, intr),
+                                                  det(self.weights_ux, intr), det(self.weights_uy, intr),
+                                                  self.img_h, self.img_w)
+            self.intr_inv_adj = Kinv
+            return K, pose, calib
         return (self.add_weights2intr(self.img_h, self.img_w, adj=intr), self.add_weights2pose(adj=extr),
                 self.add_weights2calib_pose(adj=calib_extr))
 

@@ -196,3 +196,23 @@ class RaygenFn(torch.autograd.Function):
         pose, kinv, pix = ctx.saved_tensors
         d_pose, d_kinv = ops.raygen_bwd(pose, kinv, pix, ctx.W, g_d.contiguous(), g_o.contiguous())
         return d_pose, d_kinv, None, None
+
+
+class CameraFn(torch.autograd.Function):
+    """K, Kinv, pose, calib_pose = f(weights_pose, weights_pose_intr, weights_fx, weights_fy, weights_ux, weights_uy)
+    for all cameras in one fused kernel each way (reference: model/mc_nerf.py:171-210, 269-316)."""
+
+    @staticmethod
+    def forward(ctx, wpose, wpose_intr, wfx, wfy, wux, wuy, H, W):
+        args = [t.contiguous().float() for t in (wpose, wpose_intr, wfx, wfy, wux, wuy)]
+        K, Kinv, pose, calib = ops.camera_fwd(*args, H, W)
+        ctx.save_for_backward(*args)
+        ctx.hw = (H, W)
+        ctx.set_materialize_grads(False)
+        return K, Kinv, pose, calib
+
+    @staticmethod
+    def backward(ctx, dK, dKinv, dpose, dcalib):
+        args = ctx.saved_tensors
+        grads = ops.camera_bwd(*args, ctx.hw[0], ctx.hw[1], dK, dKinv, dpose, dcalib)
+        return tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[:6])) + (None, None)

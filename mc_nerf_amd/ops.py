@@ -216,3 +216,25 @@ def cap_gather(idx: Tensor, perm: Tensor, keep: int):
     _lib.call("mcnerf_cap_gather", _p(idx, torch.int32), _p(perm, torch.int64), int(keep), _p(idx2, torch.int32),
               _p(count, torch.int32), _stream())
     return idx2, count
+
+
+def camera_fwd(wpose: Tensor, wpose_intr: Tensor, wfx: Tensor, wfy: Tensor, wux: Tensor, wuy: Tensor, H: int, W: int):
+    """-> K [C,3,3], Kinv [C,3,3], pose [C,3,4], calib_pose [C,3,4]"""
+    C, dev = wpose.shape[0], wpose.device
+    K = torch.empty(C, 3, 3, dtype=torch.float32, device=dev)
+    Kinv = torch.empty_like(K)
+    pose = torch.empty(C, 3, 4, dtype=torch.float32, device=dev)
+    calib = torch.empty_like(pose)
+    _lib.call("mcnerf_camera_fwd", _p(wpose), _p(wpose_intr), _p(wfx), _p(wfy), _p(wux), _p(wuy), C, int(H), int(W),
+              _p(K), _p(Kinv), _p(pose), _p(calib), _stream())
+    return K, Kinv, pose, calib
+
+
+def camera_bwd(wpose, wpose_intr, wfx, wfy, wux, wuy, H: int, W: int, dK, dKinv, dpose, dcalib):
+    C = wpose.shape[0]
+    outs = [torch.empty_like(t) for t in (wpose, wpose_intr, wfx, wfy, wux, wuy)]
+    c = lambda t: None if t is None else t.contiguous()
+    dK, dKinv, dpose, dcalib = c(dK), c(dKinv), c(dpose), c(dcalib)
+    _lib.call("mcnerf_camera_bwd", _p(wpose), _p(wpose_intr), _p(wfx), _p(wfy), _p(wux), _p(wuy), C, int(H), int(W),
+              _p(dK), _p(dKinv), _p(dpose), _p(dcalib), *[_p(o) for o in outs], _stream())
+    return outs

@@ -104,3 +104,28 @@ def test_barf_weights_and_host_settings():
     assert torch.equal(m.z_vals_f, torch.linspace(1.0, 8.0, 128)) and m.settings.samples_f == 128
     with pytest.raises(Exception):
         m(torch.zeros(4, 3), torch.zeros(4, 3), 0, 1.0)          # CPU tensors: fails loudly, no fallback
+
+
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    """save_model writes {'model_nerf': MC_Model.state_dict()} (model/mc_nerf.py:738-752); demo mode loads it back
+    through the prefix-stripping rewrite (:577-584, 815-837)."""
+    from mc_nerf_amd.model import MC_Model, NeRF_Model
+    sp = S.make_sys_param("cpu", samples=32, scale=2, batch=16, H=8, W=8, coarse=(4, 32, [2]), fine=(8, 64, [4]),
+                          root_weight=str(tmp_path))
+    torch.manual_seed(1)
+    m = MC_Model(sp)
+    path = m.nerf.save_model(m, epoch=3)
+    ck = torch.load(path, map_location="cpu")
+    assert list(ck.keys()) == ["model_nerf"] and len(ck["model_nerf"]) == 46
+    sp2 = dict(sp, mode=1, demo_ckpt=path)
+    torch.manual_seed(2)                               # different init: everything must come from the checkpoint
+    n = NeRF_Model(sp2)
+    for k, v in m.nerf.nerf_fine.state_dict().items():
+        assert torch.equal(n.nerf_fine.state_dict()[k], v)
+    for k, v in m.nerf.nerf_coarse.state_dict().items():
+        assert torch.equal(n.nerf_coarse.state_dict()[k], v)
+    # a checkpoint made from plain nn.Linear modules with the reference's names loads as well
+    ref_sd = {k: v.clone() for k, v in ck["model_nerf"].items()}
+    m2 = MC_Model(sp)
+    m2.load_state_dict(ref_sd)
+    assert torch.equal(m2.nerf.nerf_fine.flat_params()[:5], m.nerf.nerf_fine.flat_params()[:5])

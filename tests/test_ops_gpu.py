@@ -266,3 +266,36 @@ def test_fused_radam_matches_host_arithmetic(gpu_device):
     for pc, pg in zip(cpu, gpu):
         assert maxerr(pg, pc) < 1e-6
     assert og.state[gpu[2]]["step"] == 8 and og.state[gpu[0]]["step"] == 9
+
+
+def test_camera_parametrisation_fwd_bwd(gpu_device):
+    """Fused camera kernel vs the oracle (itself pinned to the reference by golden G9), incl. abs() on a negative
+    multiplier, a zero rotation (theta = 0) and a near-pi rotation."""
+    ops = _ops()
+    dev = gpu_device
+    C, H, W = 9, 600, 800
+    g = torch.Generator().manual_seed(4)
+    wp = (torch.randn(C, 6, generator=g) * 0.8)
+    wp[1, :3] = 0.0
+    wp[2, :3] = torch.tensor([0.0, 3.1, 0.2])
+    wpi = torch.randn(C, 6, generator=g) * 0.5
+    ws = [1.0 + 0.3 * torch.randn(C, generator=g) for _ in range(4)]
+    ws[0][3] = -0.8
+    leaves = [t.clone().requires_grad_(True) for t in [wp, wpi] + ws]
+    K = O.intrinsics_from_weights(H, W, *leaves[2:])
+    pose, calib = O.se3_to_SE3(leaves[0]), O.se3_to_SE3(leaves[1])
+    Kinv = O.inverse_intrinsic(K)
+    gK, gKi = torch.randn(C, 3, 3, generator=g), torch.randn(C, 3, 3, generator=g) * 100.0
+    gp, gc = torch.randn(C, 3, 4, generator=g), torch.randn(C, 3, 4, generator=g)
+    ((K * gK).sum() + (Kinv * gKi).sum() + (pose * gp).sum() + (calib * gc).sum()).backward()
+    dl = [t.detach().to(dev) for t in leaves]
+    K2, Ki2, p2, c2 = ops.camera_fwd(*dl, H, W)
+    assert maxerr(K2, K) < 1e-4 and maxerr(p2, pose) < 2e-6 and maxerr(c2, calib) < 2e-6
+    assert maxerr(Ki2, Kinv) < 1e-7 + 1e-6 * float(Kinv.abs().max())
+    grads = ops.camera_bwd(*dl, H, W, gK.to(dev), gKi.to(dev), gp.to(dev), gc.to(dev))
+    for got, leaf in zip(grads, leaves):
+        ref = leaf.grad
+        assert maxerr(got, ref) < 2e-5 * max(1.0, float(ref.abs().max())), (maxerr(got, ref), float(ref.abs().max()))
+    # null upstreams are allowed
+    g2 = ops.camera_bwd(*dl, H, W, None, None, gp.to(dev), None)
+    assert float(g2[1].abs().max()) == 0.0 and float(g2[2].abs().max()) == 0.0 and maxerr(g2[0], leaves[0].grad) > 0
