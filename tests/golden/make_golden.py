@@ -263,8 +263,74 @@ def g9_cameras():
         g_weights_ux=cam.weights_ux.grad, g_weights_uy=cam.weights_uy.grad)
 
 
+# ----------------------------------------------------------------------------- G11: full MC_Model step
+def g11_mc_model_step():
+    """MC_Model.forward in the GLOBAL_OPTIM stage + MC_NeRF_Loss + backward, from the actual reference."""
+    from mc_nerf_amd import synthetic as S
+    H, W, B, cam = 24, 32, 96, 7
+    sp = S.make_sys_param("cpu", samples=32, scale=2, batch=B, H=H, W=W, coarse=(4, 32, [2]), fine=(8, 64, [4]),
+                          barf_start=0.2, barf_end=0.9)
+    torch.manual_seed(3)
+    model = MC_Model(sp)
+    S.init_cameras_near_gt(model, noise=0.02, seed=1)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0], seed=2)
+    g = torch.Generator().manual_seed(11)
+    gt_img = torch.rand(1, H * W, 3, generator=g)
+    data = (gt_img, torch.tensor([cam]), wpts, pts, wpts, pts)
+    with Capture() as c:
+        torch.manual_seed(5)
+        loss_dict, intr_show, pose_show, rays_valid = model(data, 20, "GLOBAL_OPTIM_EPOCH", 0.6)
+    loss = MC_NeRF_Loss(sp)(loss_dict, "GLOBAL_OPTIM_EPOCH")
+    loss.backward()
+    rn = c.of("randn")
+    arrs = dict(H=H, W=W, B=B, cam=cam, cur_ratio=0.6, barf=np.array([0.2, 0.9]), gt_img=gt_img, wpts=wpts, pts=pts,
+                rand_idx=c.of("randperm")[0][:B], jitter=c.of("uniform")[0], eps_c=rn[0], eps_sel=rn[1], eps_f=rn[2],
+                loss=loss, rgb_c=loss_dict["rgb"][0], rgb_f=loss_dict["rgb"][1], reproj=loss_dict["intr"][0],
+                K=intr_show[1], pose=pose_show[1], rays_valid_d=rays_valid[0][::37], rays_valid_o=rays_valid[1][:1])
+    for k, v in state.items():
+        arrs["p." + k] = v
+    for k, p in model.named_parameters():
+        arrs["g." + k] = p.grad if p.grad is not None else np.zeros(0, np.float32)
+    npz("g11_mc_model_step", **arrs)
+
+
+# ----------------------------------------------------------------------------- G12: RAdam + loss
+def g12_radam():
+    g = torch.Generator().manual_seed(12)
+    shapes = [(7, 5), (5,), (1, 9), (1,)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    init = [p.detach().clone() for p in ps]
+    opt = RAdam(ps, lr=3e-3, weight_decay=4e-4)
+    grads = []
+    for step in range(12):
+        gs = [torch.randn(s, generator=g) for s in shapes]
+        grads.append(gs)
+        for p, gr in zip(ps, gs):
+            p.grad = gr.clone()
+        if step == 5:
+            ps[2].grad = None                       # a skipped tensor keeps its own step counter
+        opt.step()
+    arrs = {}
+    for i in range(len(shapes)):
+        arrs[f"init{i}"] = init[i]
+        arrs[f"final{i}"] = ps[i].detach()
+        arrs[f"grads{i}"] = torch.stack([gs[i] for gs in grads])
+    # loss
+    a, b, gt = (torch.rand(40, 3, generator=g) for _ in range(3))
+    pd, pg = torch.rand(1, 6, 5, 2, generator=g) * 800, torch.rand(1, 6, 5, 2, generator=g) * 800
+    L = MC_NeRF_Loss(dict(data_img_h=600, data_img_w=800))
+    arrs.update(rgb_c=a, rgb_f=b, rgb_gt=gt, pd=pd, pg=pg,
+                loss_cam=L({"intr": [pd, pg], "extr": [pd * 0.9, pg]}, "CAM_PARAM_EPOCH"),
+                loss_global=L({"intr": [pd, pg], "rgb": [a, b, gt]}, "GLOBAL_OPTIM_EPOCH"),
+                loss_coarse_only=L({"rgb": [a, None, gt]}, "FINE_TUNE_EPOCH"))
+    npz("g12_radam_loss", **arrs)
+
+
 def main():
     torch.set_num_threads(4)
+    g11_mc_model_step()
+    g12_radam()
     g1_embed()
     g3_mlp()
     g4_s2w()

@@ -220,3 +220,53 @@ def test_mc_model_demo_call(gpu_device):
     rgb, depth, opacity = model(torch.tensor([5]))
     assert rgb.shape == (480, 3) and depth.shape == (480, 1) and opacity.shape == (480, 1)
     assert rgb.device.type == "cpu" and bool(torch.isfinite(rgb).all()) and float(opacity.min()) >= 0.0
+
+
+def test_mc_model_step_matches_reference_golden(gpu_device, monkeypatch):
+    """MC_Model.forward (GLOBAL_OPTIM) + loss + backward against the values captured from the ACTUAL reference
+    (g11): same parameters, same pixel subset, same jitter / noise draws."""
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd.model import MC_Model, MC_NeRF_Loss, RAdam
+    import mc_nerf_amd.model.mc_nerf as mm
+    g = load_golden("g11_mc_model_step")
+    dev = gpu_device
+    H, W, B, cam = int(g["H"]), int(g["W"]), int(g["B"]), int(g["cam"])
+    sp = S.make_sys_param(dev, samples=32, scale=2, batch=B, H=H, W=W, coarse=(4, 32, [2]), fine=(8, 64, [4]),
+                          barf_start=float(g["barf"][0]), barf_end=float(g["barf"][1]))
+    model = MC_Model(sp).to(dev)
+    model.load_state_dict({k[2:]: t(v) for k, v in g.items() if k.startswith("p.")})
+    idx = t(g["rand_idx"])
+    monkeypatch.setattr(mm.torch, "randperm", lambda n, device=None: idx.to(device))
+    draws = {k: t(g[k]).to(dev) for k in ("jitter", "eps_c", "eps_sel", "eps_f")}
+    orig = model.nerf.render_rays_train
+    model.nerf.render_rays_train = lambda d, o, e, r, only_coarse=False: orig(d, o, e, r, only_coarse, **draws)
+    data = (t(g["gt_img"]), torch.tensor([cam]), t(g["wpts"]), t(g["pts"]), t(g["wpts"]), t(g["pts"]))
+    loss_dict, intr_show, pose_show, rays_valid = model(data, 20, "GLOBAL_OPTIM_EPOCH", float(g["cur_ratio"]))
+    assert err(intr_show[1], g["K"]) < 1e-3 and err(pose_show[1], g["pose"]) < 1e-5
+    assert err(loss_dict["intr"][0], g["reproj"]) < 5e-3
+    assert err(loss_dict["rgb"][0], g["rgb_c"]) < TOL and err(loss_dict["rgb"][1], g["rgb_f"]) < TOL
+    assert err(rays_valid[0][::37], g["rays_valid_d"]) < 1e-6 and err(rays_valid[1][:1], g["rays_valid_o"]) < 1e-6
+    loss = MC_NeRF_Loss(sp)(loss_dict, "GLOBAL_OPTIM_EPOCH")
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5
+    loss.backward()
+    for n, p in model.named_parameters():
+        ref = g["g." + n]
+        if ref.size == 0:
+            continue
+        assert err(p.grad, ref) < 2e-4 * max(1.0, float(np.abs(ref).max())), n
+
+
+def test_fused_radam_matches_reference_trajectory(gpu_device):
+    from mc_nerf_amd.model import RAdam
+    g = load_golden("g12_radam_loss")
+    dev = gpu_device
+    ps = [torch.nn.Parameter(t(g[f"init{i}"]).clone().to(dev)) for i in range(4)]
+    opt = RAdam(ps, lr=3e-3, weight_decay=4e-4)
+    for step in range(12):
+        for i, p in enumerate(ps):
+            p.grad = t(g[f"grads{i}"][step]).clone().to(dev)
+        if step == 5:
+            ps[2].grad = None
+        opt.step()
+    for i, p in enumerate(ps):
+        assert err(p, g[f"final{i}"]) < 1e-6
