@@ -116,22 +116,27 @@ __device__ __forceinline__ void mcn_gemm_seg(f32x16 (&acc)[NI][MI], const float*
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) xoff[mi] = (mrow0 + mi * 32 + r) * xw;
     const int sw = (mrow0 + r) & 15;            // rows of all mi tiles share (row & 15): tiles are 32 rows apart
+    // one running pointer per n-tile (advanced 1 KiB per k-step, loads use small immediate offsets): indexing P
+    // with the unrolled k-step would keep dozens of precomputed 64-bit addresses live
+    const f32x4* pa[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        a0[ni] = P[(ni * KS) * 64 + lane];
-        a1[ni] = P[(ni * KS + (KS > 1 ? 1 : 0)) * 64 + lane];
+        pa[ni] = P + (ni * KS) * 64 + lane;
+        a0[ni] = pa[ni][0];
+        a1[ni] = pa[ni][KS > 1 ? 64 : 0];
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) b_n[mi] = *reinterpret_cast<const f32x4*>(&X[xoff[mi] + (((kchunk0 + h) ^ sw) << 2)]);
-#pragma unroll 2
     for (int ks = 0; ks < KS; ++ks) {
         f32x4 a_c[NI], b[MI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) { a_c[ni] = a0[ni]; a0[ni] = a1[ni]; }
         if (ks + 2 < KS) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) a1[ni] = P[(ni * KS + ks + 2) * 64 + lane];
+            for (int ni = 0; ni < NI; ++ni) a1[ni] = pa[ni][128];
         }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) pa[ni] += 64;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) b[mi] = b_n[mi];
         if (ks + 1 < KS) {
@@ -139,6 +144,9 @@ __device__ __forceinline__ void mcn_gemm_seg(f32x16 (&acc)[NI][MI], const float*
             for (int mi = 0; mi < MI; ++mi)
                 b_n[mi] = *reinterpret_cast<const f32x4*>(&X[xoff[mi] + (((kchunk0 + 2 * (ks + 1) + h) ^ sw) << 2)]);
         }
+        // pin the pipeline: hipcc otherwise sinks the prefetches next to their consumers (vmcnt(0)/lgkmcnt(0)
+        // one MFMA after each load) and every k-step exposes the L2 and LDS latency
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -146,6 +154,7 @@ __device__ __forceinline__ void mcn_gemm_seg(f32x16 (&acc)[NI][MI], const float*
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[ni][i], b[mi][i], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
