@@ -169,7 +169,7 @@ def main():
         # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes of this same command, collected and
         # corrected as MI355X_MICROARCH.md prescribes (see profiles/*_pmc_traffic.json for the method)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
         if os.path.exists(tpath) and args.rays == 32768:
             names = {"mlp_fwd<256>": "mlp_fwd_kernel<256, true>", "mlp_bwd<256>": "mlp_bwd_kernel<256>"}
             kern = json.load(open(tpath))["kernels"]
@@ -189,7 +189,7 @@ def main():
                        "parallelism": f"dp{world} (cameras sharded, 1 flat all-reduce/step)"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC, profiles/r01b_pmc_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (PMC, profiles/r01c_pmc_traffic.json)",
                          "kernel_ms": kern_ms,
                          "step_algorithmic_tflops": 3 * (F_FINE * k_mean + F_COARSE * args.rays * 64) / 1e12},
         }
