@@ -270,3 +270,16 @@ def test_fused_radam_matches_reference_trajectory(gpu_device):
         opt.step()
     for i, p in enumerate(ps):
         assert err(p, g[f"final{i}"]) < 1e-6
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_share_one_gpu_data_parallel(gpu_device):
+    """N > 1 path with the real HIP backward: two gloo ranks on one GPU (scripts/two_rank_one_gpu.py) - the arena
+    is filled by the kernels, one all-reduce averages it, parameters stay bit-identical across ranks."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "two_rank_one_gpu.py")], capture_output=True,
+                       text=True, timeout=580)
+    assert r.returncode == 0 and "check: OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
