@@ -115,7 +115,8 @@ def main():
     C = model.train_numb
     wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0])
     wpts, pts = wpts.to(dev), pts.to(dev)
-    imgs = torch.rand(4, H * W, 3, device=dev)      # synthetic GT images (throughput does not depend on them)
+    from mc_nerf_amd.data import DeviceImageSet
+    images = DeviceImageSet.synthetic(C, H, W, dev, channels=4, seed=7)     # uint8 RGBA resident in HBM (282 MB)
     cams = D.shard_cameras(C, 0, rank, world, seed=42)
     timer = KernelTimer()
     timer.install()
@@ -123,7 +124,7 @@ def main():
 
     def step(i):
         cam = cams[i % len(cams)]
-        data = (imgs[cam % 4].unsqueeze(0), torch.tensor([cam]), wpts, pts, wpts, pts)
+        data = (images, torch.tensor([cam]), wpts, pts, wpts, pts)
         loss_dict, _, _, _ = model(data, 20, "GLOBAL_OPTIM_EPOCH", 0.6)
         loss = loss_fn(loss_dict, "GLOBAL_OPTIM_EPOCH")
         opt.zero_grad(set_to_none=True)

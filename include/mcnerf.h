@@ -121,6 +121,11 @@ int mcnerf_select_fine(const float* w_sel, const uint32_t* wmax_bits, float thre
 /* The random cap of model/mc_nerf.py:630-632: idx_out[i] = idx_in[perm[i]], i < keep; *count = keep. */
 int mcnerf_cap_gather(const int32_t* idx_in, const int64_t* perm, int keep, int32_t* idx_out, int32_t* count, void* stream);
 
+/* Ground-truth colours of n pixels of ONE uint8 image resident in HBM:
+ * image [H*W, channels] (channels 3 = RGB, 4 = RGBA composited on white as data/data_read.py:130-137),
+ * pix [n] int64 -> out [n,3] fp32.  Replaces the per-step H2D image copy + gather (model/mc_nerf.py:379, 80). */
+int mcnerf_gather_gt(const uint8_t* image, int channels, const int64_t* pix, int n, float* out, void* stream);
+
 /* Fused camera parametrisation of all C cameras.
  * Replaces add_weights2intr / add_weights2pose / add_weights2calib_pose / se3_to_SE3 / taylor_A,B,C /
  * inverse_intrinsic (model/mc_nerf.py:171-210, 269-316):

@@ -150,6 +150,11 @@ int mcnerf_cap_gather(const int32_t* idx_in, const int64_t* perm, int keep, int3
     return check("mcnerf_cap_gather", mcn_launch_cap_gather((const int2*)idx_in, (const long long*)perm, keep, (int2*)idx_out, count, (hipStream_t)stream));
 }
 
+int mcnerf_gather_gt(const uint8_t* image, int channels, const int64_t* pix, int n, float* out, void* stream) {
+    REQ(image && pix && out && n >= 0 && (channels == 3 || channels == 4), "mcnerf_gather_gt");
+    return check("mcnerf_gather_gt", mcn_launch_gather_gt(image, channels, (const long long*)pix, n, out, (hipStream_t)stream));
+}
+
 int mcnerf_camera_fwd(const float* wpose, const float* wpose_intr, const float* wfx, const float* wfy, const float* wux,
                       const float* wuy, int C, int H, int W, float* K, float* Kinv, float* pose, float* calib, void* stream) {
     REQ(wpose && wpose_intr && wfx && wfy && wux && wuy && K && Kinv && pose && calib && C >= 0 && H > 0 && W > 0, "mcnerf_camera_fwd");

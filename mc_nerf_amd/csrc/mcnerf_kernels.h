@@ -164,3 +164,5 @@ struct McnCameraGrads {
 };
 hipError_t mcn_launch_camera_fwd(const McnCameraArgs& a, hipStream_t st);
 hipError_t mcn_launch_camera_bwd(const McnCameraArgs& a, const McnCameraGrads& g, hipStream_t st);
+
+hipError_t mcn_launch_gather_gt(const unsigned char* img, int channels, const long long* pix, int n, float* out, hipStream_t st);

@@ -203,3 +203,29 @@ hipError_t mcn_launch_raygen_bwd(const McnRaygenBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(raygen_bwd_kernel, dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------ device-resident images
+// GT colour of the selected pixels of one camera straight from uint8 images kept in HBM:
+//   rgb = rgb8/255 * a + (1 - a),  a = alpha8/255   (RGBA composited on white, data/data_read.py:130-137;
+//   ToTensor's /255 first, then the blend in fp32, as the reference does), or rgb8/255 for 3-channel images.
+// Replaces the 7.7 MB/step H2D copy of a float image plus `gt_rgbs.reshape(-1,3)[rand_idx]` (model/mc_nerf.py:379, 80).
+__global__ __launch_bounds__(256) void gather_gt_kernel(const unsigned char* __restrict__ img, int channels,
+                                                        const long long* __restrict__ pix, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char* p = img + (size_t)pix[i] * channels;
+    const float r = (float)p[0] / 255.0f, g = (float)p[1] / 255.0f, b = (float)p[2] / 255.0f;
+    if (channels == 4) {
+        const float a = (float)p[3] / 255.0f;
+        out[i * 3 + 0] = r * a + (1.0f - a);
+        out[i * 3 + 1] = g * a + (1.0f - a);
+        out[i * 3 + 2] = b * a + (1.0f - a);
+    } else {
+        out[i * 3 + 0] = r; out[i * 3 + 1] = g; out[i * 3 + 2] = b;
+    }
+}
+hipError_t mcn_launch_gather_gt(const unsigned char* img, int channels, const long long* pix, int n, float* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_gt_kernel, dim3((n + 255) / 256), dim3(256), 0, st, img, channels, pix, n, out);
+    return hipGetLastError();
+}

@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.distributed as dist
 
 from .. import ops
+from ..data import DeviceImageSet
 from .net_block import CorseFine_NeRF, SinCosEmbedding
 from .render import CameraFn, RaygenFn, RenderSettings, RenderTrainFn, render_test
 
@@ -228,7 +229,9 @@ class MC_Model(nn.Module):
 
     def _forward_train(self, data, epoch, epoch_type, cur_ratio):
         cam = int(data[1].reshape(-1)[0])          # read the camera id on the host side, before the H2D copy
-        gt_rgbs, img_id, intr_wpts, intr_pts, extr_wpts, extr_pts = [t.to(self.device) for t in data]
+        images = data[0] if isinstance(data[0], DeviceImageSet) else None      # device-resident uint8 images (row f3)
+        gt_rgbs, img_id, intr_wpts, intr_pts, extr_wpts, extr_pts = [
+            t if isinstance(t, DeviceImageSet) else t.to(self.device) for t in data]
         loss_dict = {}
         emb = self.nerf.emmbedding_xyz
         if epoch_type == "CAM_PARAM_EPOCH":
@@ -248,7 +251,8 @@ class MC_Model(nn.Module):
             rand_idx = torch.randperm(self.img_h * self.img_w, device=self.device)[: self.batch]
             rays_d, rays_o = RaygenFn.apply(self.pose_adj[cam], kinv, rand_idx, self.img_w)
             rgbs_c, rgbs_f = self.nerf(rays_d, rays_o, epoch, cur_ratio if joint else 1)
-            loss_dict["rgb"] = [rgbs_c, rgbs_f, gt_rgbs.reshape(-1, 3)[rand_idx]]
+            gt = images.gather(cam, rand_idx) if images is not None else gt_rgbs.reshape(-1, 3)[rand_idx]
+            loss_dict["rgb"] = [rgbs_c, rgbs_f, gt]
             self.opt_idx = 1 if joint else 2
         # validation rays of the same index, every step, as the reference (:97-99)
         with torch.no_grad():

@@ -238,3 +238,11 @@ def camera_bwd(wpose, wpose_intr, wfx, wfy, wux, wuy, H: int, W: int, dK, dKinv,
     _lib.call("mcnerf_camera_bwd", _p(wpose), _p(wpose_intr), _p(wfx), _p(wfy), _p(wux), _p(wuy), C, int(H), int(W),
               _p(dK), _p(dKinv), _p(dpose), _p(dcalib), *[_p(o) for o in outs], _stream())
     return outs
+
+
+def gather_gt(image_u8: Tensor, pix: Tensor) -> Tensor:
+    """image_u8 [H*W, 3|4] uint8 on the device, pix [n] int64 -> [n,3] fp32 (RGBA blended on white)."""
+    n = pix.numel()
+    out = torch.empty(n, 3, dtype=torch.float32, device=pix.device)
+    _lib.call("mcnerf_gather_gt", _p(image_u8, torch.uint8), int(image_u8.shape[-1]), _p(pix, torch.int64), n, _p(out), _stream())
+    return out

@@ -299,3 +299,22 @@ def test_camera_parametrisation_fwd_bwd(gpu_device):
     # null upstreams are allowed
     g2 = ops.camera_bwd(*dl, H, W, None, None, gp.to(dev), None)
     assert float(g2[1].abs().max()) == 0.0 and float(g2[2].abs().max()) == 0.0 and maxerr(g2[0], leaves[0].grad) > 0
+
+
+def test_gather_gt_from_device_resident_images(gpu_device):
+    """uint8 RGBA / RGB images in HBM -> fp32 GT of selected pixels, against the reference loader's arithmetic
+    (ToTensor's /255 then rgb*a + (1-a), data/data_read.py:130-137)."""
+    from mc_nerf_amd.data import DeviceImageSet
+    dev = gpu_device
+    g = torch.Generator().manual_seed(0)
+    H, W = 20, 30
+    for ch in (4, 3):
+        u8 = torch.randint(0, 256, (3, H * W, ch), dtype=torch.uint8, generator=g)
+        ds = DeviceImageSet(u8.to(dev), H, W)
+        pix = torch.randperm(H * W, generator=g)[:257]
+        f = u8[1].float() / 255.0
+        ref = f[:, :3] * f[:, 3:] + (1 - f[:, 3:]) if ch == 4 else f
+        got = ds.gather(1, pix.to(dev))
+        assert maxerr(got, ref[pix]) == 0.0
+        assert maxerr(ds.full_image(2), (u8[2].float() / 255.0)[:, :3] * ((u8[2].float() / 255.0)[:, 3:] if ch == 4 else 1)
+                      + ((1 - u8[2].float()[:, 3:] / 255.0) if ch == 4 else 0)) < 1e-7
