@@ -29,14 +29,18 @@ SIGNATURES = {
     "mcnerf_tile_rows": (_I, [_I]),
     "mcnerf_param_offsets": (_I, [_I, _I, _I, _P]),
     "mcnerf_pack_weights": (_I, [_I, _I, _I, _P, _P, _P]),
+    "mcnerf_pack_weights_f16x3": (_I, [_I, _I, _I, _P, _P, _P]),
     "mcnerf_raygen_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "mcnerf_raygen_bwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "mcnerf_mlp_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
+    "mcnerf_mlp_fwd_f16x3": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
     "mcnerf_mlp_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,
                             _P, _P, _P, _P, _P]),
+    "mcnerf_mlp_bwd_f16x3": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,
+                                  _P, _P, _P, _P, _P, _P]),
     "mcnerf_mlp_dw": (_I, [_I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P]),
     "mcnerf_composite_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "mcnerf_composite_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "mcnerf_composite_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "mcnerf_select_fine": (_I, [_P, _P, c_float, _I, _I, _I, c_float, _P, _P, _P, _P, _P, _P]),
     "mcnerf_cap_gather": (_I, [_P, _P, _I, _P, _P, _P]),
     "mcnerf_gather_gt": (_I, [_P, _I, _P, _I, _P, _P]),

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(McnCompositeBwdArgs 
     const f32x4* sr = reinterpret_cast<const f32x4*>(a.sig_rgb) + (size_t)n * S;
     f32x4* dst = reinterpret_cast<f32x4*>(a.d_sig_rgb) + (size_t)n * S;
     float carryT = 1.f;
+    float gmx = 0.f;                       // max |gradient| written by this lane (scale of the split-f16 backward)
     for (int base = 0; base < S; base += 64) {
         const int j = base + lane;
         const bool ok = j < S;
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(McnCompositeBwdArgs 
             sT[j] = T; sU[j] = u; sE[j] = ex * delta * dsp; sDW[j] = dw; sDWW[j] = dw * w;
             f32x4 o; o[0] = 0.f; o[1] = w * g0; o[2] = w * g1; o[3] = w * g2;
             dst[j] = o;
+            gmx = fmaxf(gmx, fmaxf(fabsf(o[1]), fmaxf(fabsf(o[2]), fabsf(o[3]))));
         }
     }
     // suffix pass (each lane re-reads only what it wrote: no barrier needed within the wave)
@@ -171,8 +173,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(McnCompositeBwdArgs 
         carryR += __shfl(inc, 0);
         if (ok) {
             const float dalpha = sDW[j] * sT[j] - R / sU[j];
-            a.d_sig_rgb[((size_t)n * S + j) * 4] = dalpha * sE[j];
+            const float dsig = dalpha * sE[j];
+            a.d_sig_rgb[((size_t)n * S + j) * 4] = dsig;
+            gmx = fmaxf(gmx, fabsf(dsig));
         }
+    }
+    if (a.gmax_bits) {
+        gmx = wave_max(gmx);
+        if (lane == 0 && gmx < 3e38f) atomicMax(a.gmax_bits, __float_as_uint(gmx));
     }
 }
 

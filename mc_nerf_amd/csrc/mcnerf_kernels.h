@@ -23,6 +23,7 @@ struct McnMlpFwdArgs {
     unsigned int* mask_save;  // [(depth+2)][capacity][width/32] ReLU masks (bit c of word g = column 32g+c is > 0)
 };
 hipError_t mcn_launch_mlp_fwd(const McnMlpFwdArgs& a, hipStream_t st);
+hipError_t mcn_launch_mlp_fwd_h(const McnMlpFwdArgs& a, hipStream_t st);     // split-f16 mode: a.packed = mcn_launch_pack_h output
 int mcn_mlp_tile_rows(int width);
 
 struct McnMlpBwdArgs {
@@ -48,8 +49,10 @@ struct McnMlpBwdArgs {
     float* dsh_save;          // [capacity][32] gradient of the sh.2 outputs (cols 0..26) and of sigma_raw (col 27)
     float* d_rays_o;          // [n_rays,3] accumulated with atomics (may be null)
     float* d_rays_d;          // [n_rays,3]
+    const unsigned int* gmax_bits;   // split-f16 mode only: float bits of max|d_out| over the launch (device scalar)
 };
 hipError_t mcn_launch_mlp_bwd(const McnMlpBwdArgs& a, hipStream_t st);
+hipError_t mcn_launch_mlp_bwd_h(const McnMlpBwdArgs& a, hipStream_t st);     // split-f16 mode
 
 struct McnDwArgs {
     McnLayout lay;
@@ -65,6 +68,7 @@ struct McnDwArgs {
 hipError_t mcn_launch_dw(const McnDwArgs& a, hipStream_t st);
 
 hipError_t mcn_launch_pack(const McnLayout& lay, const float* params, float* packed, hipStream_t st);
+hipError_t mcn_launch_pack_h(const McnLayout& lay, const float* params, void* packed_f16, hipStream_t st);   // split-f16 (mcnerf_h.h)
 
 struct McnCompositeArgs {
     const float* sig_rgb;     // [N,S,4]
@@ -92,6 +96,7 @@ struct McnCompositeBwdArgs {
     int N, S;
     int white_back;
     float* d_sig_rgb;         // [N,S,4]
+    unsigned int* gmax_bits;  // running max of |d_sig_rgb| as float bits (for the split-f16 backward), or null
 };
 hipError_t mcn_launch_composite_bwd(const McnCompositeBwdArgs& a, hipStream_t st);
 

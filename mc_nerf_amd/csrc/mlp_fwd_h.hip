@@ -1,0 +1,265 @@
+// Fused NeRF MLP forward, split-f16 precision mode ("f16x3", see mcnerf_h.h): same structure, tile geometry
+// and outputs as mlp_fwd.hip, but every GEMM runs as three v_mfma_f32_32x32x16_f16 per product on split
+// operands (packed split weights from L2, split activations in LDS) with fp32 accumulation, bias, ReLU and
+// epilogues.  Saved activations / masks / encodings stay fp32 / identical in format, so the backward and
+// weight-gradient kernels are interchangeable between the two precision modes.
+#include "mcnerf_h.h"
+#include "mcnerf_kernels.h"
+
+template <int WIDTH>
+struct FwdSmemH {
+    using G = McnGeom<WIDTH>;
+    static constexpr int MT = G::WM * G::MI * 32;
+    static constexpr int NT = G::WN * G::WM * 64;       // threads per workgroup
+    static constexpr int XW = WIDTH > 64 ? WIDTH : 64;
+    static constexpr int oX = 0;
+    static constexpr int oXyz = oX + MT * XW;          // (X region: Xh [MT][XW] f16 then Xl [MT][XW] f16 = MT*XW floats)
+    static constexpr int oDir = oXyz + MT * 4;         // [MT][4]  dx,dy,dz,-
+    static constexpr int oSig = oDir + MT * 4;         // [WN][MT] partial sigma
+    static constexpr int oSh = oSig + G::WN * MT;      // [MT][33] sh coefficients
+    static constexpr int oAddr = oSh + MT * 33;        // [MT] int: ray*S + j  (or -1)
+    static constexpr int total = oAddr + MT;
+    static constexpr size_t bytes = (size_t)total * 4;
+};
+
+// Writes the 63(+1 pad) encoded channels of every tile row into the split LDS tile (and, on the first pass
+// of a training forward, into enc_save as fp32).  Channel order as in mlp_fwd.hip / model/net_block.py:22-33.
+template <int MT, int XW, bool SAVE_ENC>
+__device__ __forceinline__ void write_encoding_h(_Float16* Xh, _Float16* Xl, const float* sxyz, const float* barf_w, int tid, int nthreads,
+                                                 float* enc_save, long long row0, long long total) {
+    auto put = [&](int m, int ch, float v) {
+        _Float16 hi, lo;
+        mcn_split(v * MCN_SX, hi, lo);
+        const int o = mcn_hoff<XW>(m, ch >> 3) + (ch & 7);
+        Xh[o] = hi; Xl[o] = lo;
+        if (SAVE_ENC && row0 + m < total) enc_save[(size_t)(row0 + m) * MCN_ENCP + ch] = v;
+    };
+    for (int it = tid; it < MT * 30; it += nthreads) {
+        const int m = it / 30, cf = it - m * 30;
+        const int c = cf / 10, f = cf - c * 10;
+        const float v = sxyz[m * 4 + c] * (float)(1 << f);     // exact: power-of-two scale
+        float s, co;
+        sincosf(v, &s, &co);
+        const float w = barf_w[f];
+        put(m, 3 + c * 20 + f, s * w);
+        put(m, 3 + c * 20 + 10 + f, co * w);
+    }
+    for (int it = tid; it < MT * 4; it += nthreads) {
+        const int m = it >> 2, c = it & 3;
+        put(m, c == 3 ? 63 : c, (c == 3) ? 0.f : sxyz[m * 4 + c]);
+    }
+}
+
+// Layer epilogue shared by the trunk layers and the two head hidden layers: v = relu(acc + bias);
+//   TO_LDS : write v into the LDS tile (next layer's input)
+//   SAVE   : store v (dW operand) and its 1-bit ReLU mask (backward chain) to the workspaces
+//   DOT    : accumulate sum_n v[n] * w2[n] per sample (the 1-wide sigma output layer, lane-local)
+// A lane holds 16 of the 32 columns of its row per tile (the other 16 sit in lane ^ 32), so the mask halves
+// are combined with one cross-lane move.
+template <int WIDTH, int NI, int MI, bool TO_LDS, bool SAVE, bool DOT>
+__device__ __forceinline__ void layer_epilogue_h(f32x16 (&acc)[NI][MI], const float* __restrict__ bias, const float* __restrict__ w2,
+                                               _Float16* Xh, _Float16* Xl, float* __restrict__ save, unsigned int* __restrict__ msave,
+                                               float (&dot)[MI], int mrow0, int ncol0, long long row0, long long total, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) dot[mi] = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = mrow0 + mi * 32 + r;
+            const bool ok = row0 + m < total;
+            unsigned bits = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n4 = ncol0 + ni * 32 + 8 * q + 4 * h;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n4);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[ni][mi][4 * q + e] * (1.0f / (MCN_SW * MCN_SX)) + bb[e], 0.f);
+                    if (SAVE) bits |= (v[e] > 0.f ? 1u : 0u) << (8 * q + 4 * h + e);
+                }
+                if (DOT) {
+                    const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + n4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dot[mi] = fmaf(v[e], ww[e], dot[mi]);
+                }
+                if (TO_LDS) mcn_store_split4<(WIDTH > 64 ? WIDTH : 64)>(Xh, Xl, m, n4, v);
+                if (SAVE && ok) *reinterpret_cast<f32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = v;
+            }
+            if (SAVE) {
+                const unsigned w = bits | (unsigned)__shfl_xor((int)bits, 32);
+                if (h == 0 && ok) msave[(size_t)(row0 + m) * (WIDTH / 32) + (ncol0 >> 5) + ni] = w;
+            }
+        }
+}
+
+template <int WIDTH, bool SAVE>
+__global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) void mlp_fwd_h_kernel(McnMlpFwdArgs a) {
+    using G = McnGeom<WIDTH>;
+    using SM = FwdSmemH<WIDTH>;
+    constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN, NT = SM::NT, WAVES = NT / 64;
+    constexpr int KSH = WIDTH / 16;     // k-steps (of 16) of a hidden segment
+    constexpr int KSE = MCN_ENCP / 16;  // ... of the encoded segment
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Xh = reinterpret_cast<_Float16*>(smem + SM::oX);
+    _Float16* Xl = Xh + MT * XW;
+    float* sxyz = smem + SM::oXyz;
+    float* sdir = smem + SM::oDir;
+    float* ssig = smem + SM::oSig;
+    float* ssh = smem + SM::oSh;
+    int* saddr = reinterpret_cast<int*>(smem + SM::oAddr);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int mrow0 = wm * MI * 32;
+    const int ncol0 = wn * NI * 32;
+    const long long total = a.count ? (long long)min(*a.count, a.max_rows) : (long long)a.n_rays * a.S;
+    const long long row0 = (long long)blockIdx.x * MT;
+    if (row0 >= total) return;
+    const McnLayout& L = a.lay;
+    const float* __restrict__ prm = a.params;
+    const h8* __restrict__ pk = reinterpret_cast<const h8*>(a.packed);     // split-f16 packed weights (16-byte units)
+
+    // ---- per-sample setup: position, direction, output address
+    for (int m = tid; m < MT; m += NT) {
+        const long long g = row0 + m;
+        float x = 0.f, y = 0.f, z = 0.f, dx = 0.f, dy = 0.f, dz = 1.f, zv = 0.f;
+        int addr = -1;
+        if (g < total) {
+            int ray, j;
+            if (a.idx) { const int2 rj = a.idx[g]; ray = rj.x; j = rj.y; }
+            else { ray = (int)(g / a.S); j = (int)(g - (long long)ray * a.S); }
+            zv = a.zgrid[j];
+            if (a.jitter) zv = __fadd_rn(zv, a.jitter[ray]);
+            dx = a.rays_d[ray * 3 + 0]; dy = a.rays_d[ray * 3 + 1]; dz = a.rays_d[ray * 3 + 2];
+            // o + d*z with separate roundings, as the reference's broadcasted mul then add (mc_nerf.py:602)
+            x = __fadd_rn(a.rays_o[ray * 3 + 0], __fmul_rn(dx, zv));
+            y = __fadd_rn(a.rays_o[ray * 3 + 1], __fmul_rn(dy, zv));
+            z = __fadd_rn(a.rays_o[ray * 3 + 2], __fmul_rn(dz, zv));
+            addr = ray * a.S + j;
+        }
+        sxyz[m * 4 + 0] = x; sxyz[m * 4 + 1] = y; sxyz[m * 4 + 2] = z; sxyz[m * 4 + 3] = zv;
+        sdir[m * 4 + 0] = dx; sdir[m * 4 + 1] = dy; sdir[m * 4 + 2] = dz; sdir[m * 4 + 3] = 0.f;
+        saddr[m] = addr;
+    }
+    __syncthreads();
+    write_encoding_h<MT, XW, SAVE>(Xh, Xl, sxyz, a.barf_w, tid, NT, a.enc_save, row0, total);
+    __syncthreads();
+
+    f32x16 acc[NI][MI];
+    // ---- trunk
+    for (int l = 0; l < L.depth; ++l) {
+        mcn_zero<NI, MI>(acc);
+        if (l == 0) {
+            mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSE, pk + (L.fEnc0 >> 2) + (wn * NI) * KSE * 128, lane);
+        } else {
+            mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSH, pk + (L.fH[l] >> 2) + (wn * NI) * KSH * 128, lane);
+            if (l == L.skip) {
+                __syncthreads();                       // everyone finished reading h from X
+                write_encoding_h<MT, XW, false>(Xh, Xl, sxyz, a.barf_w, tid, NT, nullptr, row0, total);
+                __syncthreads();
+                mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSE, pk + (L.fEncS >> 2) + (wn * NI) * KSE * 128, lane);
+            }
+        }
+        __syncthreads();
+        float unused[MI];
+        layer_epilogue_h<WIDTH, NI, MI, true, SAVE, false>(acc, prm + L.pB[l], nullptr, Xh, Xl,
+            SAVE ? a.act_save + (size_t)l * a.act_stride : nullptr,
+            SAVE ? a.mask_save + (size_t)l * (a.act_stride / 32) : nullptr, unused, mrow0, ncol0, row0, total, lane);
+        __syncthreads();
+    }
+
+    // ---- sigma head: hidden layer on MFMA, the 1-wide output layer lane-local on the VALU
+    {
+        mcn_zero<NI, MI>(acc);
+        mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSH, pk + (L.fS1 >> 2) + (wn * NI) * KSH * 128, lane);
+        float s[MI];
+        layer_epilogue_h<WIDTH, NI, MI, false, SAVE, true>(acc, prm + L.pBs1, prm + L.pWs2, Xh, Xl,
+            SAVE ? a.act_save + (size_t)L.depth * a.act_stride : nullptr,
+            SAVE ? a.mask_save + (size_t)L.depth * (a.act_stride / 32) : nullptr, s, mrow0, ncol0, row0, total, lane);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            s[mi] += __shfl_xor(s[mi], 32);
+            if (h == 0) ssig[wn * MT + mrow0 + mi * 32 + r] = s[mi];
+        }
+    }
+    // ---- SH head hidden layer (reads the same trunk output still resident in X)
+    {
+        mcn_zero<NI, MI>(acc);
+        mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSH, pk + (L.fC1 >> 2) + (wn * NI) * KSH * 128, lane);
+        __syncthreads();
+        float unused[MI];
+        layer_epilogue_h<WIDTH, NI, MI, true, SAVE, false>(acc, prm + L.pBc1, nullptr, Xh, Xl,
+            SAVE ? a.act_save + (size_t)(L.depth + 1) * a.act_stride : nullptr,
+            SAVE ? a.mask_save + (size_t)(L.depth + 1) * (a.act_stride / 32) : nullptr, unused, mrow0, ncol0, row0, total, lane);
+        __syncthreads();
+    }
+    // ---- SH output layer (27 -> 32 padded outputs): one 32-row m-tile per wave
+    for (int mt = wave; mt < MT / 32; mt += WAVES) {
+        f32x16 a1[1][1];
+        mcn_zero<1, 1>(a1);
+        mcn_gemm_seg_h<XW, 1, 1>(a1, Xh, Xl, mt * 32, 0, KSH, pk + (L.fC2 >> 2), lane);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = (e & 3) + 8 * (e >> 2) + 4 * h;
+            ssh[(mt * 32 + r) * 33 + n] = a1[0][0][e] * (1.0f / (MCN_SW * MCN_SX));
+        }
+    }
+    __syncthreads();
+    // ---- per-sample epilogue: sigma, SH colour, sigmoid
+    for (int m = tid; m < MT; m += NT) {
+        const long long g = row0 + m;
+        if (g >= total) continue;
+        float sigma = prm[L.pBs2];
+#pragma unroll
+        for (int w = 0; w < WN; ++w) sigma += ssig[w * MT + m];
+        float sh[MCN_NSH];
+#pragma unroll
+        for (int i = 0; i < MCN_NSH; ++i) sh[i] = ssh[m * 33 + i] + prm[L.pBc2 + i];
+        float b[9];
+        mcn_sh_basis(sdir[m * 4 + 0], sdir[m * 4 + 1], sdir[m * 4 + 2], b);
+        f32x4 o;
+        o[0] = sigma;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float pre = b[0] * sh[9 * c];
+#pragma unroll
+            for (int i = 1; i < 9; ++i) pre += b[i] * sh[9 * c + i];
+            o[1 + c] = 1.0f / (1.0f + expf(-pre));
+        }
+        *reinterpret_cast<f32x4*>(a.out + (size_t)saddr[m] * 4) = o;
+        if (SAVE) {
+            float* dst = a.sh_save + (size_t)g * MCN_NSHP;
+#pragma unroll
+            for (int i = 0; i < MCN_NSH; ++i) dst[i] = sh[i];
+        }
+    }
+}
+
+template <int WIDTH>
+static hipError_t launch_fwd_h(const McnMlpFwdArgs& a, long long max_rows, hipStream_t st) {
+    using SM = FwdSmemH<WIDTH>;
+    const int grid = (int)((max_rows + SM::MT - 1) / SM::MT);
+    if (grid <= 0) return hipSuccess;
+    const bool save = a.act_save != nullptr;
+    auto kern = save ? mlp_fwd_h_kernel<WIDTH, true> : mlp_fwd_h_kernel<WIDTH, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SM::NT), SM::bytes, st, a);
+    return hipGetLastError();
+}
+
+hipError_t mcn_launch_mlp_fwd_h(const McnMlpFwdArgs& a, hipStream_t st) {
+    const long long max_rows = a.count ? (long long)a.max_rows : (long long)a.n_rays * a.S;
+    switch (a.lay.width) {
+        case 256: return launch_fwd_h<256>(a, max_rows, st);
+        case 128: return launch_fwd_h<128>(a, max_rows, st);
+        case 64:  return launch_fwd_h<64>(a, max_rows, st);
+        case 32:  return launch_fwd_h<32>(a, max_rows, st);
+    }
+    return hipErrorInvalidValue;
+}
+

@@ -63,8 +63,12 @@ class NeRF_Model(nn.Module):
         self.emmbedding_xyz = SinCosEmbedding(sys_param)
         self.nerf_coarse = CorseFine_NeRF(sys_param, type="coarse")
         self.nerf_fine = CorseFine_NeRF(sys_param, type="fine")
+        # "precision" is this build's own sys_param key (absent in the reference's config): "f32" or "f16x3"
+        self.precision = sys_param.get("precision", "f32")
+        if self.precision not in ops.PRECISIONS:
+            raise ValueError(f"precision must be one of {ops.PRECISIONS}")
         self.settings = RenderSettings(self.samples_c, self.sample_scale, float(self.weight_thresh),
-                                       float(self.sigma_default), bool(self.white_back))
+                                       float(self.sigma_default), bool(self.white_back), precision=self.precision)
         self.last_selection = None
         self.last_flat_grads = None
         self.grad_arena = None            # set per step by distributed.FlatGradSync.prepare()

@@ -28,6 +28,7 @@ class RenderSettings:
     sigma_default: float
     white_back: bool
     max_fine_per_ray: int = 128      # model/mc_nerf.py:630
+    precision: str = "f32"           # "f32": exact-fp32 MFMA; "f16x3": split-f16 MFMA (fp32-grade, ~3x faster chain kernels)
 
     @property
     def samples_f(self):
@@ -73,10 +74,11 @@ class RenderTrainFn(torch.autograd.Function):
         # ---- coarse pass (dense [N,Sc] grid)
         net_c = model_c.net
         flat_c = model_c.flat_params()
-        packed_c = ops.pack_weights(net_c, flat_c)
+        prec = st.precision
+        packed_c = ops.pack_weights(net_c, flat_c, precision=prec)
         out_c = torch.empty(N, st.samples_c, 4, dtype=torch.float32, device=dev)
         save_c = ops.alloc_save(net_c, N * st.samples_c, dev) if need_grad else None
-        ops.mlp_fwd(net_c, flat_c, packed_c, rays_o, rays_d, owner.z_vals_c, jit, barf_w, out_c, save=save_c)
+        ops.mlp_fwd(net_c, flat_c, packed_c, rays_o, rays_d, owner.z_vals_c, jit, barf_w, out_c, save=save_c, precision=prec)
         rgb_c, depth_c, _, w_sel, wmax = ops.composite_fwd(out_c, rays_d, owner.z_vals_c, jit, eps_c,
                                                           None if only_coarse else eps_sel, st.white_back,
                                                           want_depth=only_coarse)
@@ -94,10 +96,10 @@ class RenderTrainFn(torch.autograd.Function):
         idx, count, out_f, max_rows = select_and_cap(st, w_sel, wmax, N, cap_perm, train=True)
         net_f = model_f.net
         flat_f = model_f.flat_params()
-        packed_f = ops.pack_weights(net_f, flat_f)
+        packed_f = ops.pack_weights(net_f, flat_f, precision=prec)
         save_f = ops.alloc_save(net_f, max_rows, dev) if need_grad else None
         ops.mlp_fwd(net_f, flat_f, packed_f, rays_o, rays_d, owner.z_vals_f, jit, barf_w, out_f,
-                    idx=idx, count=count, max_rows=max_rows, save=save_f)
+                    idx=idx, count=count, max_rows=max_rows, save=save_f, precision=prec)
         rgb_f, _, _, _, _ = ops.composite_fwd(out_f, rays_d, owner.z_vals_f, jit, eps_f, None, st.white_back)
         if need_grad:
             ctx.save_for_backward(rays_d, rays_o, jit, eps_c, barf_w, out_c, flat_c, packed_c,
@@ -132,11 +134,11 @@ class RenderTrainFn(torch.autograd.Function):
             if d_rgb is None:
                 return
             net = model.net
-            d_out = ops.composite_bwd(out, zgrid, jit, eps, d_rgb.contiguous(), st.white_back)
+            d_out, gmax = ops.composite_bwd(out, zgrid, jit, eps, d_rgb.contiguous(), st.white_back, want_gmax=True)
             dy = torch.empty_like(save.act)
             dsh = torch.empty_like(save.sh)
             ops.mlp_bwd(net, flat, packed, rays_o, rays_d, zgrid, jit, barf_w, out, d_out, save, dy, dsh,
-                        d_o, d_d, idx=idx, count=count, max_rows=max_rows)
+                        d_o, d_d, idx=idx, count=count, max_rows=max_rows, precision=st.precision, gmax=gmax)
             rows = max_rows if idx is not None else N * zgrid.numel()
             ops.mlp_dw(net, save, dy, dsh, grads, rows, count=count)
 
@@ -165,13 +167,14 @@ def render_test(owner, model_c, model_f, rays_d, rays_o, eps_c, eps_sel, eps_f):
     barf_w = owner.emmbedding_xyz.barf_weights(1).to(dev)
     net_c, net_f = model_c.net, model_f.net
     flat_c, flat_f = model_c.flat_params(), model_f.flat_params()
-    packed_c, packed_f = ops.pack_weights(net_c, flat_c), ops.pack_weights(net_f, flat_f)
+    prec = st.precision
+    packed_c, packed_f = ops.pack_weights(net_c, flat_c, precision=prec), ops.pack_weights(net_f, flat_f, precision=prec)
     out_c = torch.empty(N, st.samples_c, 4, dtype=torch.float32, device=dev)
-    ops.mlp_fwd(net_c, flat_c, packed_c, rays_o, rays_d, owner.z_vals_c, None, barf_w, out_c)
+    ops.mlp_fwd(net_c, flat_c, packed_c, rays_o, rays_d, owner.z_vals_c, None, barf_w, out_c, precision=prec)
     _, _, _, w_sel, wmax = ops.composite_fwd(out_c, rays_d, owner.z_vals_c, None, eps_c, eps_sel, st.white_back)
     idx, count, out_f, max_rows = select_and_cap(st, w_sel, wmax, N, None, train=False)
     ops.mlp_fwd(net_f, flat_f, packed_f, rays_o, rays_d, owner.z_vals_f, None, barf_w, out_f,
-                idx=idx, count=count, max_rows=max_rows)
+                idx=idx, count=count, max_rows=max_rows, precision=prec)
     rgb, depth, opacity, _, _ = ops.composite_fwd(out_f, rays_d, owner.z_vals_f, None, eps_f, None, st.white_back,
                                                   want_depth=True)
     owner.last_selection = (idx, count)

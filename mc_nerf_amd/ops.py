@@ -99,10 +99,16 @@ def flatten_params(net: Net, tensors, device) -> Tensor:
 
 
 # --------------------------------------------------------------------------- ops
-def pack_weights(net: Net, params: Tensor, packed: Optional[Tensor] = None) -> Tensor:
+PRECISIONS = ("f32", "f16x3")
+
+
+def pack_weights(net: Net, params: Tensor, packed: Optional[Tensor] = None, precision: str = "f32") -> Tensor:
+    """Packed weights for the given precision mode (same byte size in both: fp32 fragments or split-f16 fragments)."""
+    assert precision in PRECISIONS
     if packed is None:
         packed = torch.empty(packed_count(net), dtype=torch.float32, device=params.device)
-    _lib.call("mcnerf_pack_weights", *net.triple, _p(params), _p(packed), _stream())
+    name = "mcnerf_pack_weights" if precision == "f32" else "mcnerf_pack_weights_f16x3"
+    _lib.call(name, *net.triple, _p(params), _p(packed), _stream())
     return packed
 
 
@@ -143,10 +149,11 @@ def alloc_save(net: Net, capacity: int, device) -> MlpSave:
 
 def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, zgrid: Tensor,
             jitter: Optional[Tensor], barf_w: Tensor, out: Tensor, idx: Optional[Tensor] = None,
-            count: Optional[Tensor] = None, max_rows: int = 0, save: Optional[MlpSave] = None) -> None:
+            count: Optional[Tensor] = None, max_rows: int = 0, save: Optional[MlpSave] = None,
+            precision: str = "f32") -> None:
     n_rays, S = rays_d.shape[0], zgrid.numel()
     assert out.numel() == n_rays * S * 4
-    _lib.call("mcnerf_mlp_fwd", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
+    _lib.call("mcnerf_mlp_fwd" if precision == "f32" else "mcnerf_mlp_fwd_f16x3", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
               _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
               _p(out), _p(save.act) if save else None, save.capacity if save else 0,
               _p(save.enc) if save else None, _p(save.sh) if save else None,
@@ -156,12 +163,17 @@ def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
 def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, zgrid: Tensor,
             jitter: Optional[Tensor], barf_w: Tensor, out: Tensor, d_out: Tensor, save: MlpSave,
             dy: Tensor, dsh: Tensor, d_rays_o: Optional[Tensor], d_rays_d: Optional[Tensor],
-            idx: Optional[Tensor] = None, count: Optional[Tensor] = None, max_rows: int = 0) -> None:
+            idx: Optional[Tensor] = None, count: Optional[Tensor] = None, max_rows: int = 0,
+            precision: str = "f32", gmax: Optional[Tensor] = None) -> None:
     n_rays, S = rays_d.shape[0], zgrid.numel()
-    _lib.call("mcnerf_mlp_bwd", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
-              _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
-              _p(out), _p(d_out), _p(save.mask, torch.int32), save.capacity, _p(save.enc), _p(save.sh),
-              _p(dy), _p(dsh), _p(d_rays_o), _p(d_rays_d), _stream())
+    args = [*net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
+            _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
+            _p(out), _p(d_out), _p(save.mask, torch.int32), save.capacity, _p(save.enc), _p(save.sh),
+            _p(dy), _p(dsh), _p(d_rays_o), _p(d_rays_d)]
+    if precision == "f32":
+        _lib.call("mcnerf_mlp_bwd", *args, _stream())
+    else:
+        _lib.call("mcnerf_mlp_bwd_f16x3", *args, _p(gmax, torch.int32), _stream())
 
 
 def mlp_dw(net: Net, save: MlpSave, dy: Tensor, dsh: Tensor, grads: Tensor, rows: int,
@@ -186,12 +198,14 @@ def composite_fwd(sig_rgb: Tensor, rays_d: Tensor, zgrid: Tensor, jitter: Option
 
 
 def composite_bwd(sig_rgb: Tensor, zgrid: Tensor, jitter: Optional[Tensor], eps: Tensor, d_rgb: Tensor,
-                  white_back: bool = True) -> Tensor:
+                  white_back: bool = True, want_gmax: bool = False):
+    """-> d_sig_rgb [N,S,4] (and, with want_gmax, the int32 word holding max|d_sig_rgb| as float bits)"""
     N, S = d_rgb.shape[0], zgrid.numel()
     d = torch.empty(N, S, 4, dtype=torch.float32, device=d_rgb.device)
+    gmax = torch.zeros(1, dtype=torch.int32, device=d_rgb.device) if want_gmax else None
     _lib.call("mcnerf_composite_bwd", _p(sig_rgb), _p(zgrid), _p(jitter), _p(eps), _p(d_rgb), N, S,
-              int(bool(white_back)), _p(d), _stream())
-    return d
+              int(bool(white_back)), _p(d), _p(gmax, torch.int32), _stream())
+    return (d, gmax) if want_gmax else d
 
 
 def select_fine(w_sel: Tensor, wmax: Tensor, thresh: float, scale: int, sigma_default: float,

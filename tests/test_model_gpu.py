@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def build_model(g, dev, mode=0):
+def build_model(g, dev, mode=0, precision="f32"):
     from mc_nerf_amd.model import NeRF_Model
     cfg = cfg_from_golden(g)
-    sp = make_sys_param(cfg, device=str(dev), mode=0)
+    sp = make_sys_param(cfg, device=str(dev), mode=0, precision=precision)
     m = NeRF_Model(sp).to(dev)
     pc, pf = nets_from_golden(g, cfg)
     m.nerf_coarse.load_state_dict(pc)
@@ -33,11 +33,12 @@ def err(a, b):
 TRAIN = ["g7_train_s64x2_small", "g7_train_s32x5_small_barf", "g7_train_s32x5_cap", "g7_train_s64x2_full"]
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("name", TRAIN)
-def test_render_rays_train_matches_reference(gpu_device, name):
+def test_render_rays_train_matches_reference(gpu_device, name, precision):
     g = load_golden(name)
     dev = gpu_device
-    m, cfg, pc, pf = build_model(g, dev)
+    m, cfg, pc, pf = build_model(g, dev, precision=precision)
     d = t(g["rays_d"]).to(dev).requires_grad_(True)
     o = t(g["rays_o"]).to(dev).requires_grad_(True)
     kw = dict(jitter=t(g["jitter"]).to(dev), eps_c=t(g["eps_c"]).to(dev), eps_sel=t(g["eps_sel"]).to(dev),
@@ -90,11 +91,12 @@ def test_render_coarse_only(gpu_device):
     assert err(depth_c, g["depth_c"]) < TOL
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("name", ["g8_test_s64x2_small", "g8_test_s64x2_full", "g8_test_s128x5_small"])
-def test_render_rays_test_matches_reference(gpu_device, name):
+def test_render_rays_test_matches_reference(gpu_device, name, precision):
     g = load_golden(name)
     dev = gpu_device
-    m, cfg, pc, pf = build_model(g, dev)
+    m, cfg, pc, pf = build_model(g, dev, precision=precision)
     rgb, depth, opacity = m.render_rays_test(t(g["rays_d"]).to(dev), t(g["rays_o"]).to(dev), m.nerf_coarse, m.nerf_fine,
                                              eps_c=t(g["eps_c"]).to(dev), eps_sel=t(g["eps_sel"]).to(dev),
                                              eps_f=t(g["eps_f"]).to(dev))

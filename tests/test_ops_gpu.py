@@ -54,9 +54,10 @@ def test_layout_matches_header(gpu_device):
         assert ops.packed_count(net) > 0
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("width", [32, 64, 128, 256])
 @pytest.mark.parametrize("barf", [False, True])
-def test_mlp_fwd_dense(gpu_device, width, barf):
+def test_mlp_fwd_dense(gpu_device, width, barf, precision):
     ops = _ops()
     dev = gpu_device
     nc = NETS[width]
@@ -75,12 +76,12 @@ def test_mlp_fwd_dense(gpu_device, width, barf):
     ref, hidden, sh = O.mlp_forward(p, nc, O.embed(xyz, step_r, cfg), dirs, return_hidden=True)
 
     flat = flat_params(nc, p, dev)
-    packed = ops.pack_weights(net, flat)
+    packed = ops.pack_weights(net, flat, precision=precision)
     out = torch.full((N, S, 4), float("nan"), device=dev)
     save = ops.alloc_save(net, N * S, dev)
     bw = O.barf_weights(step_r, cfg).to(dev)
     ops.mlp_fwd(net, flat, packed, o.to(dev), d.to(dev), zg.to(dev), jitter.reshape(-1).to(dev).contiguous(), bw,
-                out, save=save)
+                out, save=save, precision=precision)
     torch.cuda.synchronize()
     # layer by layer first (localises a failure), then the output
     act = save.act.view(nc.depth + 2, save.capacity, width)
@@ -93,7 +94,8 @@ def test_mlp_fwd_dense(gpu_device, width, barf):
     assert maxerr(out.view(-1, 4), ref) < 2e-5
     # the no-save instantiation gives the same output
     out2 = torch.empty_like(out)
-    ops.mlp_fwd(net, flat, packed, o.to(dev), d.to(dev), zg.to(dev), jitter.reshape(-1).to(dev).contiguous(), bw, out2)
+    ops.mlp_fwd(net, flat, packed, o.to(dev), d.to(dev), zg.to(dev), jitter.reshape(-1).to(dev).contiguous(), bw, out2,
+                precision=precision)
     assert torch.equal(out, out2)
 
 
@@ -156,8 +158,9 @@ def test_select_fine(gpu_device):
     assert int(c2.item()) == 1 and torch.equal(idx2.cpu().long(), ref[perm[:1]])
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("width", [32, 64, 128, 256])
-def test_mlp_fwd_bwd_indexed(gpu_device, width):
+def test_mlp_fwd_bwd_indexed(gpu_device, width, precision):
     """Fine-pass mode: (ray, sample) list + device count; forward, dX chain, dW against autograd."""
     ops = _ops()
     dev = gpu_device
@@ -184,7 +187,7 @@ def test_mlp_fwd_bwd_indexed(gpu_device, width):
     (ref * gout).sum().backward()
 
     flat = flat_params(nc, {k: v.detach() for k, v in p.items()}, dev)
-    packed = ops.pack_weights(net, flat)
+    packed = ops.pack_weights(net, flat, precision=precision)
     cap = K + 17
     idx_d = torch.zeros(cap, 2, dtype=torch.int32, device=dev)
     idx_d[:K] = idx.to(torch.int32).to(dev)
@@ -193,7 +196,7 @@ def test_mlp_fwd_bwd_indexed(gpu_device, width):
     save = ops.alloc_save(net, cap, dev)
     bw = O.barf_weights(step_r, cfg).to(dev)
     od, dd, zd, jd = o.detach().to(dev), d.detach().to(dev), zg.to(dev), jitter.reshape(-1).to(dev).contiguous()
-    ops.mlp_fwd(net, flat, packed, od, dd, zd, jd, bw, out, idx=idx_d, count=count, max_rows=cap, save=save)
+    ops.mlp_fwd(net, flat, packed, od, dd, zd, jd, bw, out, idx=idx_d, count=count, max_rows=cap, save=save, precision=precision)
     got = out[r.to(dev), j.to(dev)]
     assert maxerr(got, ref) < 2e-5
     assert torch.all(out[~sel.to(dev)] == 7.0)          # untouched elsewhere
@@ -205,8 +208,9 @@ def test_mlp_fwd_bwd_indexed(gpu_device, width):
     dsh = torch.empty_like(save.sh)
     d_o = torch.zeros(N, 3, device=dev)
     d_d = torch.zeros(N, 3, device=dev)
+    gmax = d_out.abs().max().reshape(1).view(torch.int32)        # what composite_bwd hands to the split-f16 backward
     ops.mlp_bwd(net, flat, packed, od, dd, zd, jd, bw, out, d_out, save, dy, dsh, d_o, d_d,
-                idx=idx_d, count=count, max_rows=cap)
+                idx=idx_d, count=count, max_rows=cap, precision=precision, gmax=gmax)
     ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count)
     torch.cuda.synchronize()
     scale_o = float(o.grad.abs().max())
