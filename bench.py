@@ -43,9 +43,10 @@ class KernelTimer:
         timer = self
 
         def timed(name, *args):
-            if not timer.enabled or name not in ("mcnerf_mlp_fwd", "mcnerf_mlp_bwd", "mcnerf_mlp_dw"):
+            base = name.replace("_f16x3", "")
+            if not timer.enabled or base not in ("mcnerf_mlp_fwd", "mcnerf_mlp_bwd", "mcnerf_mlp_dw"):
                 return orig(name, *args)
-            key = (name, args[1])           # (entry point, net width)
+            key = (base, args[1])           # (entry point, net width)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             r = orig(name, *args)
@@ -94,6 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=32768, help="rays per step per GPU (config `batch`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+                    help="MFMA mode of the MLP chain kernels: exact fp32, or split-f16 (fp32-grade, 3 f16 MFMAs per product)")
     args = ap.parse_args()
 
     from mc_nerf_amd import distributed as D
@@ -105,7 +108,7 @@ def main():
 
     torch.manual_seed(42 + rank)                   # main.py:274-277: seed + rank
     H = W = 800
-    sp = S.make_sys_param(dev, samples=64, scale=2, batch=args.rays, H=H, W=W, barf_mask=False)
+    sp = S.make_sys_param(dev, samples=64, scale=2, batch=args.rays, H=H, W=W, barf_mask=False, precision=args.precision)
     model = MC_Model(sp).to(dev)
     S.init_cameras_near_gt(model, noise=1e-3)
     loss_fn = MC_NeRF_Loss(sp)

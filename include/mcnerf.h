@@ -121,6 +121,12 @@ int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows
                   const float* act_save, const float* enc_save, const float* dy_save, const float* dsh_save,
                   long long capacity, float* grads, void* stream);
 
+/* mcnerf_mlp_dw in the split-f16 precision mode (same fp32 operands; fragments are split to hi/lo f16 in
+ * registers, three f16 MFMAs per product); gmax_bits as for mcnerf_mlp_bwd_f16x3. */
+int mcnerf_mlp_dw_f16x3(int depth, int width, int skip, const int32_t* count, int rows,
+                        const float* act_save, const float* enc_save, const float* dy_save, const float* dsh_save,
+                        long long capacity, float* grads, const uint32_t* gmax_bits, void* stream);
+
 /* Alpha compositing of [N,S] samples per ray.
  * Replaces NeRF_Model.inference's compositing (model/mc_nerf.py:705-727) and sigma2weights
  * (model/mc_nerf.py:729-736); the N(0,1) draws of sigma2weights are explicit inputs.

@@ -39,6 +39,7 @@ SIGNATURES = {
     "mcnerf_mlp_bwd_f16x3": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,
                                   _P, _P, _P, _P, _P, _P]),
     "mcnerf_mlp_dw": (_I, [_I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P]),
+    "mcnerf_mlp_dw_f16x3": (_I, [_I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P]),
     "mcnerf_composite_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mcnerf_composite_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "mcnerf_select_fine": (_I, [_P, _P, c_float, _I, _I, _I, c_float, _P, _P, _P, _P, _P, _P]),

@@ -164,8 +164,20 @@ int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows
     McnDwArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
     a.count = count; a.rows = rows; a.act_save = act_save; a.enc_save = enc_save; a.dy_save = dy_save;
-    a.dsh_save = dsh_save; a.act_stride = (size_t)capacity * width; a.grads = grads;
+    a.dsh_save = dsh_save; a.act_stride = (size_t)capacity * width; a.grads = grads; a.split16 = false; a.gmax_bits = nullptr;
     return check("mcnerf_mlp_dw", mcn_launch_dw(a, (hipStream_t)stream));
+}
+
+int mcnerf_mlp_dw_f16x3(int depth, int width, int skip, const int32_t* count, int rows,
+                        const float* act_save, const float* enc_save, const float* dy_save, const float* dsh_save,
+                        long long capacity, float* grads, const uint32_t* gmax_bits, void* stream) {
+    REQ(net_ok(depth, width, skip), "mcnerf_mlp_dw_f16x3");
+    REQ(act_save && enc_save && dy_save && dsh_save && grads && gmax_bits && rows >= 0 && capacity >= rows, "mcnerf_mlp_dw_f16x3");
+    McnDwArgs a;
+    a.lay = mcn_make_layout(depth, width, skip);
+    a.count = count; a.rows = rows; a.act_save = act_save; a.enc_save = enc_save; a.dy_save = dy_save;
+    a.dsh_save = dsh_save; a.act_stride = (size_t)capacity * width; a.grads = grads; a.split16 = true; a.gmax_bits = gmax_bits;
+    return check("mcnerf_mlp_dw_f16x3", mcn_launch_dw(a, (hipStream_t)stream));
 }
 
 int mcnerf_composite_fwd(const float* sig_rgb, const float* rays_d, const float* zgrid, const float* jitter,

@@ -64,6 +64,8 @@ struct McnDwArgs {
     const float* dsh_save;
     size_t act_stride;
     float* grads;             // flat gradient buffer (same layout as params), accumulated with atomics
+    bool split16;             // split-f16 MFMA mode (mcnerf_h.h)
+    const unsigned int* gmax_bits;   // split-f16 mode: float bits of max|d_out| (gradient scale), device scalar
 };
 hipError_t mcn_launch_dw(const McnDwArgs& a, hipStream_t st);
 

@@ -6,7 +6,7 @@
 // rows, keeps its full (wave-tiled) dW block in MFMA accumulators for the whole chunk and issues one
 // float-atomic pass at the end (>= 512 FLOP per atomic byte, far above the atomic roofline).
 // (Design notes at the kernel.)
-#include "mcnerf_common.h"
+#include "mcnerf_h.h"
 #include "mcnerf_kernels.h"
 
 struct DwSeg {
@@ -177,6 +177,153 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Split-f16 ("f16x3", mcnerf_h.h) variant: same persistent structure, same fp32 operands in HBM and LDS; every
+// wave converts its operand fragments to hi/lo f16 in registers (v_cvt + subtract) and issues three
+// v_mfma_f32_32x32x16_f16 per 32x32x16 block.  One slab = one MFMA k-step of 16 sample rows; LDS ring of 4 slabs.
+//   dY is scaled by the per-launch power of two SG derived from max|d_out| (gradients sit far below the f16
+//   normal range), activations by MCN_SX; the accumulators are rescaled before the atomic pass.
+// At 5.3x the MFMA rate this kernel is HBM-bound (2 KB of operands per sample row and W x W segment).
+template <int N, int K>
+__global__ __launch_bounds__(512) void dw_h_kernel(DwSeg s, const int* count, int rows_cap, const unsigned int* gmax_bits) {
+    constexpr int VN = N >= 128 ? 4 : N / 32;
+    constexpr int KT = N == 32 ? (K >= 128 ? 4 : K / 32) : (K >= 64 ? 2 : 1);
+    typedef typename VecT<VN>::T AV;
+    constexpr int RS = 16;                  // LDS ring of 4 slabs: slab s is consumed while slabs s+1..s+3 are in flight
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int rows = count ? min(*count, rows_cap) : rows_cap;
+    int chunk = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+    chunk = (chunk + RS - 1) / RS * RS;
+    const int r0 = blockIdx.x * chunk;
+    if (r0 >= rows) return;
+    const int r1 = min(r0 + chunk, rows);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int NG = N / (32 * VN), KG = K / (32 * KT);
+    constexpr int G = NG * KG;
+    constexpr int MS = 8 / G;               // waves sharing one output tile take alternate slabs
+    static_assert(G >= 1 && G <= 8 && 8 % G == 0, "wave tiling");
+    const int gi = wave % G, ms = wave / G;
+    const int nbase = (gi % NG) * 32 * VN, kbase = (gi / NG) * 32 * KT;
+    constexpr int slab = RS * (N + K);
+    constexpr int n4 = N / 4, k4 = K / 4;
+    constexpr int tot4 = RS * (n4 + k4);
+    constexpr int NP = (tot4 + 511) / 512;
+
+    const float gmax = gmax_bits ? __uint_as_float(*gmax_bits) : 1.f;
+    const float sg = (gmax > 0.f && gmax < 3e38f) ? exp2f(4.f - ceilf(log2f(gmax))) : 1.f;
+
+    f32x16 acc[VN][KT];
+    mcn_zero<VN, KT>(acc);
+    float bsum[VN];
+#pragma unroll
+    for (int t = 0; t < VN; ++t) bsum[t] = 0.f;
+
+    const float* const gY = s.dY;
+    const float* const gX = s.X;
+    const int ldy = s.ldy, ldx = s.ldx;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    auto piece = [=](int i, int base_row, float* buf) {
+        const int q = tid + i * 512;
+        if ((i + 1) * 512 <= tot4 || q < tot4) {
+            const bool isY = q < RS * n4;
+            const int qq = isY ? q : q - RS * n4;
+            const int w4 = isY ? n4 : k4;
+            const int row = qq / w4, c4 = qq - row * w4;
+            const int grow = base_row + row;
+            const int rc = grow < r1 ? grow : r1 - 1;
+            const float* src = isY ? gY + (size_t)rc * ldy + 4 * c4 : gX + (size_t)rc * ldx + 4 * c4;
+            float* dst = buf + 4 * (i * 512 + (tid & ~63));
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+#define DWH_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n) : "memory")
+    // prologue: slabs 0..2 in flight, slab 0 landed
+    int nslab = (r1 - r0 + RS - 1) / RS;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) piece(i, r0, lds);
+    if (nslab > 1) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) piece(i, r0 + RS, lds + slab);
+    }
+    if (nslab > 2) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) piece(i, r0 + 2 * RS, lds + 2 * slab);
+    }
+    if (nslab > 2) DWH_WAIT_BARRIER(2 * NP); else if (nslab > 1) DWH_WAIT_BARRIER(NP); else DWH_WAIT_BARRIER(0);
+    int cur = 0;
+    for (int sidx = 0; sidx < nslab; ++sidx) {
+        const int base = r0 + sidx * RS;
+        const bool fill = sidx + 3 < nslab;                       // workgroup-uniform
+        if (fill) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) piece(i, base + 3 * RS, lds + ((cur + 3) & 3) * slab);
+        }
+        if ((sidx % MS) == ms) {                                   // wave-uniform
+            const float* sY = lds + cur * slab;
+            const float* sX = sY + RS * N;
+            // fragments: rows 8h .. 8h+7 of the slab, column = this lane's output(s) / input(s)
+            AV av[8];
+            float bv[KT][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = 8 * h + j;
+                av[j] = *reinterpret_cast<const AV*>(sY + row * N + nbase + VN * r);
+                if (base + row >= r1) av[j] = AV(0.f);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) bv[kt][j] = sX[row * K + kbase + 32 * kt + r];
+            }
+            h8 ah[VN], al[VN], bh[KT], bl[KT];
+#pragma unroll
+            for (int t = 0; t < VN; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = vget<VN>(av[j], t);
+                    bsum[t] += x;
+                    _Float16 a, b; mcn_split(x * sg, a, b); ah[t][j] = a; al[t][j] = b;
+                }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { _Float16 a, b; mcn_split(bv[kt][j] * MCN_SX, a, b); bh[kt][j] = a; bl[kt][j] = b; }
+#pragma unroll
+            for (int t = 0; t < VN; ++t)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    acc[t][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[kt], acc[t][kt], 0, 0, 0);
+                    acc[t][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[kt], acc[t][kt], 0, 0, 0);
+                    acc[t][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[kt], acc[t][kt], 0, 0, 0);
+                }
+        }
+        // everyone is done reading `cur`; the next slab has landed for every wave (2 younger slabs may be in flight)
+        const int left = nslab - 1 - sidx;       // slabs after this one
+        if (left >= 3) DWH_WAIT_BARRIER(2 * NP); else if (left == 2) DWH_WAIT_BARRIER(NP); else DWH_WAIT_BARRIER(0);
+        cur = (cur + 1) & 3;
+    }
+#undef DWH_WAIT_BARRIER
+    const float inv = 1.0f / (sg * MCN_SX);
+#pragma unroll
+    for (int t = 0; t < VN; ++t)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int k = kbase + 32 * kt + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = nbase + VN * ((e & 3) + 8 * (e >> 2) + 4 * h) + t;
+                if (n >= s.n_lo && n < s.n_real && k < s.k_real) atomicAdd(s.dW + (size_t)(n - s.n_lo) * s.ldw + k, acc[t][kt][e] * inv);
+            }
+        }
+    if (s.db && kbase == 0) {
+#pragma unroll
+        for (int t = 0; t < VN; ++t) {
+            const float b = bsum[t] + __shfl_xor(bsum[t], 32);
+            const int n = nbase + VN * r + t;
+            if (h == 0 && n >= s.n_lo && n < s.n_real) atomicAdd(s.db + (n - s.n_lo), b);
+        }
+    }
+}
+
 static int dw_num_cus() {
     static int cus = 0;
     if (!cus) {
@@ -188,19 +335,28 @@ static int dw_num_cus() {
     return cus;
 }
 
-static hipError_t launch_seg(const DwSeg& s, const int* count, int rows_cap, hipStream_t st) {
+static hipError_t launch_seg(const DwSeg& s, const int* count, int rows_cap, hipStream_t st, const unsigned int* gmax_bits = nullptr, bool split16 = false) {
     if (rows_cap <= 0) return hipSuccess;
     int grid = dw_num_cus();                                   // persistent: one workgroup per CU
     const int max_wgs = (rows_cap + DW_SLAB_ROWS - 1) / DW_SLAB_ROWS;
     if (grid > max_wgs) grid = max_wgs;
-    const size_t lds = (size_t)3 * DW_SLAB_ROWS * (s.N + s.K) * sizeof(float);
+    const size_t lds = (size_t)(split16 ? 4 : 3) * DW_SLAB_ROWS * (s.N + s.K) * sizeof(float);
 #define DW_LAUNCH(NN, KK) do { \
-        auto kern = dw_kernel<NN, KK>; \
-        if (lds > 64 * 1024) { \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e; \
-        } \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, s, count, rows_cap); } while (0)
+        if (split16) { \
+            auto kern = dw_h_kernel<NN, KK>; \
+            if (lds > 64 * 1024) { \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e != hipSuccess) return e; \
+            } \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, s, count, rows_cap, gmax_bits); \
+        } else { \
+            auto kern = dw_kernel<NN, KK>; \
+            if (lds > 64 * 1024) { \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                if (e != hipSuccess) return e; \
+            } \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, s, count, rows_cap); \
+        } } while (0)
     const int key = s.N * 1000 + s.K;
     switch (key) {
         case 256256: DW_LAUNCH(256, 256); break;
@@ -229,24 +385,24 @@ hipError_t mcn_launch_dw(const McnDwArgs& a, hipStream_t st) {
         const int ldw = mcn_in_features(D, W, L.skip, l);
         if (l == 0 || l == L.skip) {      // encoded-input columns
             DwSeg s = {dy(l), W, a.enc_save, MCN_ENCP, W, 0, W, MCN_ENCP, MCN_ENC, a.grads + L.pW[l], ldw, a.grads + L.pB[l]};
-            if ((e = launch_seg(s, a.count, a.rows, st)) != hipSuccess) return e;
+            if ((e = launch_seg(s, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
         }
         if (l > 0) {                      // hidden-input columns (after the 63 encoded ones at the skip layer)
             DwSeg s = {dy(l), W, act(l - 1), W, W, 0, W, W, W, a.grads + L.pW[l] + (l == L.skip ? MCN_ENC : 0), ldw,
                        l == L.skip ? nullptr : a.grads + L.pB[l]};
-            if ((e = launch_seg(s, a.count, a.rows, st)) != hipSuccess) return e;
+            if ((e = launch_seg(s, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
         }
     }
     {   // sigma.0 and sh.0 read the last trunk activation; sh.2 reads the sh hidden layer
         DwSeg s1 = {dy(D), W, act(D - 1), W, W, 0, W, W, W, a.grads + L.pWs1, W, a.grads + L.pBs1};
-        if ((e = launch_seg(s1, a.count, a.rows, st)) != hipSuccess) return e;
+        if ((e = launch_seg(s1, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
         DwSeg c1 = {dy(D + 1), W, act(D - 1), W, W, 0, W, W, W, a.grads + L.pWc1, W, a.grads + L.pBc1};
-        if ((e = launch_seg(c1, a.count, a.rows, st)) != hipSuccess) return e;
+        if ((e = launch_seg(c1, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
         DwSeg c2 = {a.dsh_save, MCN_NSHP, act(D + 1), W, MCN_NSHP, 0, MCN_NSH, W, W, a.grads + L.pWc2, W, a.grads + L.pBc2};
-        if ((e = launch_seg(c2, a.count, a.rows, st)) != hipSuccess) return e;
+        if ((e = launch_seg(c2, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
         // sigma.2 (1 x W): d sigma sits in the spare column 27 of dsh_save, its input is the sigma hidden layer
         DwSeg s2 = {a.dsh_save, MCN_NSHP, act(D), W, MCN_NSHP, MCN_NSH, MCN_NSH + 1, W, W, a.grads + L.pWs2, W, a.grads + L.pBs2};
-        if ((e = launch_seg(s2, a.count, a.rows, st)) != hipSuccess) return e;
+        if ((e = launch_seg(s2, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
     }
     return hipSuccess;
 }

@@ -177,9 +177,12 @@ def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
 
 
 def mlp_dw(net: Net, save: MlpSave, dy: Tensor, dsh: Tensor, grads: Tensor, rows: int,
-           count: Optional[Tensor] = None) -> None:
-    _lib.call("mcnerf_mlp_dw", *net.triple, _p(count, torch.int32), int(rows), _p(save.act), _p(save.enc),
-              _p(dy), _p(dsh), save.capacity, _p(grads), _stream())
+           count: Optional[Tensor] = None, precision: str = "f32", gmax: Optional[Tensor] = None) -> None:
+    args = [*net.triple, _p(count, torch.int32), int(rows), _p(save.act), _p(save.enc), _p(dy), _p(dsh), save.capacity, _p(grads)]
+    if precision == "f32":
+        _lib.call("mcnerf_mlp_dw", *args, _stream())
+    else:
+        _lib.call("mcnerf_mlp_dw_f16x3", *args, _p(gmax, torch.int32), _stream())
 
 
 def composite_fwd(sig_rgb: Tensor, rays_d: Tensor, zgrid: Tensor, jitter: Optional[Tensor], eps: Tensor,

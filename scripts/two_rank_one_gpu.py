@@ -61,10 +61,15 @@ def worker(rank, world, port, q):
 
 
 if __name__ == "__main__":
+    import socket
     world = 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=worker, args=(r, world, 29731, q)) for r in range(world)]
+    ps = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
     for p in ps:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))

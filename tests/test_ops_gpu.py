@@ -211,7 +211,7 @@ def test_mlp_fwd_bwd_indexed(gpu_device, width, precision):
     gmax = d_out.abs().max().reshape(1).view(torch.int32)        # what composite_bwd hands to the split-f16 backward
     ops.mlp_bwd(net, flat, packed, od, dd, zd, jd, bw, out, d_out, save, dy, dsh, d_o, d_d,
                 idx=idx_d, count=count, max_rows=cap, precision=precision, gmax=gmax)
-    ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count)
+    ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count, precision=precision, gmax=gmax)
     torch.cuda.synchronize()
     scale_o = float(o.grad.abs().max())
     assert maxerr(d_o, o.grad) < 2e-5 * max(1.0, scale_o), (maxerr(d_o, o.grad), scale_o)
