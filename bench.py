@@ -28,6 +28,14 @@ sys.path.insert(0, ROOT)
 # algorithmic FLOPs per evaluated sample, forward: 2 x weight MACs
 F_FINE, F_COARSE = 2 * 629248, 2 * 101632
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0      # ibid., "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_HBM_GBS = 8000.0              # ibid., "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
+# algorithmic HBM bytes per evaluated fine sample: fp32 operands the training step keeps for the
+# weight-gradient GEMMs (10 layer slots x 256 x 4 B) + encoded input (256 B) + SH coefficients (128 B) +
+# 1-bit ReLU masks (10 x 32 B) + output (16 B) + index (8 B)
+B_FWD = 10 * 1024 + 256 + 128 + 320 + 16 + 8
+B_BWD = 10 * 1024 + 128 + 320 + 256 + 128 + 32 + 8      # dY slots + dsh written; masks, enc, sh, out/d_out, index read
+B_DW = 2 * 1024 * 9 + 2 * (1024 + 256) + 2 * (1024 + 128)   # 9 WxW segments, 2 enc segments, sh.2 and sigma.2 segments
 
 
 class KernelTimer:
@@ -95,7 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=32768, help="rays per step per GPU (config `batch`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="MFMA mode of the MLP chain kernels: exact fp32, or split-f16 (fp32-grade, 3 f16 MFMAs per product)")
     args = ap.parse_args()
 
@@ -162,40 +170,51 @@ def main():
     if rank == 0:
         k_mean = float(torch.stack(counts).float().mean())
         ks = timer.summary()
-        # dominant kernel = the fused fine-net forward/backward/dW; report the slowest of the three against the
-        # exact-fp32 MFMA peak, using algorithmic FLOPs (2 x MACs x evaluated samples) per launch
-        cand = {"mlp_fwd<256>": (ks.get(("mcnerf_mlp_fwd", 256)), F_FINE * k_mean),
-                "mlp_bwd<256>": (ks.get(("mcnerf_mlp_bwd", 256)), F_FINE * k_mean),
-                "mlp_dw<256>": (ks.get(("mcnerf_mlp_dw", 256)), F_FINE * k_mean)}
+        # dominant kernel = the slowest of the fused fine-net forward / backward chain / weight-gradient kernels.
+        # Both roofs are evaluated with ALGORITHMIC work per launch (FLOPs: 2 x MACs x evaluated samples; bytes:
+        # the operands the kernel's contract makes it move) over the HIP-event launch time; the binding one
+        # (larger fraction) is reported.
+        cand = {"mlp_fwd<256>": (ks.get(("mcnerf_mlp_fwd", 256)), B_FWD),
+                "mlp_bwd<256>": (ks.get(("mcnerf_mlp_bwd", 256)), B_BWD),
+                "mlp_dw<256>": (ks.get(("mcnerf_mlp_dw", 256)), B_DW)}
         kern_ms = {k: v[0] for k, v in cand.items() if v[0]}
         dom = max(kern_ms, key=kern_ms.get)
-        ach = cand[dom][1] / (cand[dom][0] * 1e-3) / 1e12
+        secs = cand[dom][0] * 1e-3
+        ach_tf = F_FINE * k_mean / secs / 1e12
+        ach_gbs = cand[dom][1] * k_mean / secs / 1e9
+        mfma_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
+        if ach_tf / mfma_peak >= ach_gbs / PEAK_HBM_GBS:
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach_tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": ach_tf / mfma_peak}
+        else:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS}
+        roof["other_roof"] = {"mfma_TFLOPs": ach_tf, "mfma_frac": ach_tf / mfma_peak, "hbm_GBs": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS}
         # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes of this same command, collected and
         # corrected as MI355X_MICROARCH.md prescribes (see profiles/*_pmc_traffic.json for the method)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json" if args.precision == "f16x3" else "r01c_pmc_traffic.json")
         if os.path.exists(tpath) and args.rays == 32768:
-            names = {"mlp_fwd<256>": "mlp_fwd_kernel<256, true>", "mlp_bwd<256>": "mlp_bwd_kernel<256>"}
+            sfx = "_h" if args.precision == "f16x3" else ""
+            names = {"mlp_fwd<256>": f"mlp_fwd{sfx}_kernel<256, true>", "mlp_bwd<256>": f"mlp_bwd{sfx}_kernel<256>"}
             kern = json.load(open(tpath))["kernels"]
             if dom in names and names[dom] in kern:
                 traffic = kern[names[dom]]["hbm_bytes_per_launch"]
             elif dom == "mlp_dw<256>":
-                traffic = sum(v["hbm_bytes_per_launch"] * {"dw_kernel<256, 256>": 9, "dw_kernel<256, 64>": 2, "dw_kernel<32, 256>": 2}.get(k, 0)
+                traffic = sum(v["hbm_bytes_per_launch"] * {f"dw{sfx}_kernel<256, 256>": 9, f"dw{sfx}_kernel<256, 64>": 2, f"dw{sfx}_kernel<32, 256>": 4}.get(k, 0)
                               for k, v in kern.items())
         total_rays = args.rays * world * args.steps
         out = {
             "metric": "train rays/sec (coarse+fine, 64+128 samples)", "value": total_rays / dt, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "f16x3 (split-f16 MFMA operands, fp32 accumulate/storage)", "data": "synthetic",
             "config": {"workload": "Ball_Lego-shaped 110-view 800x800, coarse 4x128 @64 + fine 8x256 @128-grid, "
                                    "GLOBAL_OPTIM stage, fwd+bwd+allreduce+RAdam",
-                       "rays_per_step_per_gpu": args.rays, "fine_samples_per_ray": k_mean / args.rays,
+                       "precision": args.precision, "rays_per_step_per_gpu": args.rays, "fine_samples_per_ray": k_mean / args.rays,
                        "parallelism": f"dp{world} (cameras sharded, 1 flat all-reduce/step)"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC, profiles/r01c_pmc_traffic.json)",
-                         "kernel_ms": kern_ms,
-                         "step_algorithmic_tflops": 3 * (F_FINE * k_mean + F_COARSE * args.rays * 64) / 1e12},
+            "roofline": dict(roof, traffic=traffic,
+                             traffic_unit="HBM bytes per launch (rocprofv3 PMC, profiles/*_pmc_traffic.json)",
+                             kernel_ms=kern_ms,
+                             step_algorithmic_tflops=3 * (F_FINE * k_mean + F_COARSE * args.rays * 64) / 1e12),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
