@@ -89,14 +89,36 @@ __device__ __forceinline__ void mcn_gemm_seg_h(f32x16 (&acc)[NI][MI], const _Flo
     }
 }
 
-// 4 consecutive activations of row m (fp32, unscaled) -> split f16 in the LDS tile
+// "Split word": the saved-operand format of the f16x3 mode: one 32-bit word per value, hi f16 in the low half,
+// lo f16 in the high half (value = (hi + lo) / scale).  Same size and row-major layout as the fp32 workspaces,
+// so the weight-gradient kernel builds its MFMA fragments with plain half-word packs instead of conversions.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned mcn_word(_Float16 hi, _Float16 lo) {
+    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+}
+__device__ __forceinline__ float mcn_unword(unsigned w, float inv_scale) {
+    const _Float16 hi = __builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+    const _Float16 lo = __builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+    return ((float)hi + (float)lo) * inv_scale;
+}
+
+// 4 consecutive values of row m (fp32, unscaled) -> split f16 (x scale) in the LDS tile; returns the split words
 template <int XW>
-__device__ __forceinline__ void mcn_store_split4(_Float16* Xh, _Float16* Xl, int m, int n4, const f32x4& v) {
+__device__ __forceinline__ u32x4 mcn_store_split4(_Float16* Xh, _Float16* Xl, int m, int n4, const f32x4& v, float scale = MCN_SX) {
     h4 hi, lo;
+    u32x4 w;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { _Float16 a, b; mcn_split(v[e] * MCN_SX, a, b); hi[e] = a; lo[e] = b; }
+    for (int e = 0; e < 4; ++e) { _Float16 a, b; mcn_split(v[e] * scale, a, b); hi[e] = a; lo[e] = b; w[e] = mcn_word(a, b); }
     const int o = mcn_hoff<XW>(m, n4 >> 3) + (n4 & 7);
     *reinterpret_cast<h4*>(Xh + o) = hi;
     *reinterpret_cast<h4*>(Xl + o) = lo;
+    return w;
+}
+// split words of 4 values without touching LDS
+__device__ __forceinline__ u32x4 mcn_words4(const f32x4& v, float scale) {
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { _Float16 a, b; mcn_split(v[e] * scale, a, b); w[e] = mcn_word(a, b); }
+    return w;
 }
 #endif

@@ -2,7 +2,8 @@
 // structure as mlp_bwd.hip; the LDS tile holds dY as split f16 scaled by a per-launch power of two SG chosen
 // from max|d_out| (gradients are far below the f16 normal range otherwise), the transposed packed weights are
 // split f16, every GEMM is three v_mfma_f32_32x32x16_f16 per product with fp32 accumulation.  dy_save /
-// dsh_save stay fp32 and unscaled, so mlp_dw.hip is shared between the precision modes.
+// dsh_save receive SPLIT WORDS scaled by SG (mcnerf_h.h) for the split-f16 weight-gradient kernel; enc_save
+// (written by the split-f16 forward) is read back as split words.
 #include "mcnerf_h.h"
 #include "mcnerf_kernels.h"
 
@@ -24,13 +25,8 @@ struct BwdSmemH {
 
 // 4 consecutive gradients of row m (fp32, unscaled) -> split f16 scaled by sg in the LDS tile
 template <int XW>
-__device__ __forceinline__ void store_split4_s(_Float16* Xh, _Float16* Xl, int m, int n4, const f32x4& v, float sg) {
-    h4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { _Float16 a, b; mcn_split(v[e] * sg, a, b); hi[e] = a; lo[e] = b; }
-    const int o = mcn_hoff<XW>(m, n4 >> 3) + (n4 & 7);
-    *reinterpret_cast<h4*>(Xh + o) = hi;
-    *reinterpret_cast<h4*>(Xl + o) = lo;
+__device__ __forceinline__ u32x4 store_split4_s(_Float16* Xh, _Float16* Xl, int m, int n4, const f32x4& v, float sg) {
+    return mcn_store_split4<XW>(Xh, Xl, m, n4, v, sg);
 }
 
 // acc (scaled gradient wrt a post-ReLU activation) * inv -> masked by the forward's ReLU bit mask -> dy_save
@@ -63,8 +59,8 @@ __device__ __forceinline__ void mask_store_h(f32x16 (&acc)[NI][MI], const unsign
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ((w >> e) & 1u) ? acc[ni][mi][4 * q + e] * inv : 0.f;
-                store_split4_s<XW>(Xh, Xl, m, k4, v, sg);
-                if (ok) *reinterpret_cast<f32x4*>(dysave + (size_t)(row0 + m) * WIDTH + k4) = v;
+                const u32x4 w4 = store_split4_s<XW>(Xh, Xl, m, k4, v, sg);
+                if (ok) *reinterpret_cast<u32x4*>(dysave + (size_t)(row0 + m) * WIDTH + k4) = w4;      // split words, scaled by sg
             }
         }
 }
@@ -141,7 +137,8 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             dsh[MCN_NSH] = dsg;      // spare column 27 carries d sigma: the dW kernel reduces d sigma.2.{weight,bias} from it
             float* dst = a.dsh_save + (size_t)g * MCN_NSHP;
 #pragma unroll
-            for (int i = 0; i < MCN_NSHP; i += 4) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<f32x4*>(&dsh[i]);
+            for (int i = 0; i < MCN_NSHP; i += 4)            // split words scaled by sg (operand of the sh.2 / sigma.2 dW)
+                *reinterpret_cast<u32x4*>(dst + i) = mcn_words4(*reinterpret_cast<f32x4*>(&dsh[i]), sg);
         }
 #pragma unroll
         for (int c4 = 0; c4 < MCN_NSHP / 4; ++c4) {
@@ -179,8 +176,8 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ((w >> e) & 1u) ? ds * ww[e] : 0.f;
-            store_split4_s<XW>(Xh, Xl, m, 4 * c4, v, sg);
-            if (ok) *reinterpret_cast<f32x4*>(dys + (size_t)(row0 + m) * WIDTH + 4 * c4) = v;
+            const u32x4 w4 = store_split4_s<XW>(Xh, Xl, m, 4 * c4, v, sg);
+            if (ok) *reinterpret_cast<u32x4*>(dys + (size_t)(row0 + m) * WIDTH + 4 * c4) = w4;
         }
     }
     __syncthreads();
@@ -243,11 +240,11 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             const long long g = row0 + m;
             float dx = 0.f;
             if (g < total) {
-                const float* en = a.enc_save + (size_t)g * MCN_ENCP;
+                const unsigned* en = reinterpret_cast<const unsigned*>(a.enc_save) + (size_t)g * MCN_ENCP;   // split words
                 dx = Xf[mcn_swz(m, c, 64)];
 #pragma unroll
                 for (int f = 0; f < MCN_NFREQ; ++f) {
-                    const float s = en[3 + 20 * c + f], co = en[3 + 20 * c + 10 + f];
+                    const float s = mcn_unword(en[3 + 20 * c + f], 1.0f / MCN_SX), co = mcn_unword(en[3 + 20 * c + 10 + f], 1.0f / MCN_SX);
                     const float ds = Xf[mcn_swz(m, 3 + 20 * c + f, 64)], dc = Xf[mcn_swz(m, 3 + 20 * c + 10 + f, 64)];
                     dx += (float)(1 << f) * (co * ds - s * dc);
                 }

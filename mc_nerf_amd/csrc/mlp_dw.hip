@@ -100,7 +100,11 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
     // All VMEM operations of the main loop are these pieces, NP per slab per wave, in program order, so
     // "slab s+1 has landed" == at most NP (the pieces of slab s+2) still outstanding: counted vmcnt + raw
     // s_barrier (a __syncthreads() would drain vmcnt(0) and expose the HBM latency every slab).
-#define DW_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n) : "memory")
+    // (When tot4 is not a multiple of 512 the trailing waves issue only NP-1 pieces per slab, so the count
+    // allowed in flight is per wave: `full` is wave-uniform.)
+    const bool full = (tot4 % 512 == 0) || (__builtin_amdgcn_readfirstlane(tid >> 6) * 64 + (NP - 1) * 512 < tot4);
+#define DW_WAIT_ASM(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n) : "memory")
+#define DW_WAIT_BARRIER(k) do { if (full) DW_WAIT_ASM((k) * NP); else DW_WAIT_ASM((k) * (NP - 1)); } while (0)
     float* b_cur = lds;
     float* b_nxt = lds + slab;
     float* b_fill = lds + 2 * slab;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
     if (r0 + RS < r1) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) piece(i, r0 + RS, b_nxt);
-        DW_WAIT_BARRIER(NP);
+        DW_WAIT_BARRIER(1);
     } else {
         DW_WAIT_BARRIER(0);
     }
@@ -151,10 +155,11 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
             }
         }
         // everyone is done reading b_cur; slab base+RS (in b_nxt) has landed for every wave
-        if (fill) DW_WAIT_BARRIER(NP); else DW_WAIT_BARRIER(0);
+        if (fill) DW_WAIT_BARRIER(1); else DW_WAIT_BARRIER(0);
         float* t = b_cur; b_cur = b_nxt; b_nxt = b_fill; b_fill = t;
     }
 #undef DW_WAIT_BARRIER
+#undef DW_WAIT_ASM
     // accumulators -> global (float atomics; one register = two 128-byte row segments)
 #pragma unroll
     for (int t = 0; t < VN; ++t)
@@ -178,12 +183,33 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Split-f16 ("f16x3", mcnerf_h.h) variant: same persistent structure, same fp32 operands in HBM and LDS; every
-// wave converts its operand fragments to hi/lo f16 in registers (v_cvt + subtract) and issues three
-// v_mfma_f32_32x32x16_f16 per 32x32x16 block.  One slab = one MFMA k-step of 16 sample rows; LDS ring of 4 slabs.
-//   dY is scaled by the per-launch power of two SG derived from max|d_out| (gradients sit far below the f16
-//   normal range), activations by MCN_SX; the accumulators are rescaled before the atomic pass.
+// Split-f16 ("f16x3", mcnerf_h.h) variant: same persistent structure; the operands in HBM / LDS are the SPLIT
+// WORDS (hi | lo << 16) written by the split-f16 forward (activations, encodings: scaled by MCN_SX) and
+// backward (dY, dsh: scaled by the per-launch power of two SG derived from max|d_out|), so a wave builds its MFMA
+// fragments with half-word packs only and issues three v_mfma_f32_32x32x16_f16 per 32x32x16 block.
+// One slab = one MFMA k-step of 16 sample rows; LDS ring of 4 slabs; the accumulators are rescaled by
+// 1 / (SG * MCN_SX) before the atomic pass.
 // At 5.3x the MFMA rate this kernel is HBM-bound (2 KB of operands per sample row and W x W segment).
+template <int V> struct VecU;
+template <> struct VecU<1> { typedef unsigned T; };
+template <> struct VecU<2> { typedef unsigned T __attribute__((ext_vector_type(2))); };
+template <> struct VecU<4> { typedef unsigned T __attribute__((ext_vector_type(4))); };
+template <int V> __device__ __forceinline__ unsigned uget(const typename VecU<V>::T& v, int i) { return v[i]; }
+template <> __device__ __forceinline__ unsigned uget<1>(const unsigned& v, int) { return v; }
+
+// 8 split words (8 consecutive sample rows of one column) -> the hi and lo MFMA fragments (4 packs each)
+__device__ __forceinline__ void mcn_frag_from_words(const unsigned (&w)[8], h8& hi, h8& lo) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 ph, pl;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        ph[p] = __builtin_amdgcn_perm(w[2 * p + 1], w[2 * p], 0x05040100u);     // {lo16(w[2p]), lo16(w[2p+1])}
+        pl[p] = __builtin_amdgcn_perm(w[2 * p + 1], w[2 * p], 0x07060302u);     // {hi16(w[2p]), hi16(w[2p+1])}
+    }
+    hi = __builtin_bit_cast(h8, ph);
+    lo = __builtin_bit_cast(h8, pl);
+}
+
 template <int N, int K>
 __global__ __launch_bounds__(512) void dw_h_kernel(DwSeg s, const int* count, int rows_cap, const unsigned int* gmax_bits) {
     constexpr int VN = N >= 128 ? 4 : N / 32;
@@ -238,7 +264,10 @@ __global__ __launch_bounds__(512) void dw_h_kernel(DwSeg s, const int* count, in
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
         }
     };
-#define DWH_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n) : "memory")
+    // k slabs may stay in flight; the trailing waves issue NP-1 pieces per slab when tot4 % 512 != 0 (wave-uniform)
+    const bool full = (tot4 % 512 == 0) || (__builtin_amdgcn_readfirstlane(tid >> 6) * 64 + (NP - 1) * 512 < tot4);
+#define DWH_WAIT_ASM(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(n) : "memory")
+#define DWH_WAIT_BARRIER(k) do { if (full) DWH_WAIT_ASM((k) * NP); else DWH_WAIT_ASM((k) * (NP - 1)); } while (0)
     // prologue: slabs 0..2 in flight, slab 0 landed
     int nslab = (r1 - r0 + RS - 1) / RS;
 #pragma unroll
@@ -251,7 +280,7 @@ __global__ __launch_bounds__(512) void dw_h_kernel(DwSeg s, const int* count, in
 #pragma unroll
         for (int i = 0; i < NP; ++i) piece(i, r0 + 2 * RS, lds + 2 * slab);
     }
-    if (nslab > 2) DWH_WAIT_BARRIER(2 * NP); else if (nslab > 1) DWH_WAIT_BARRIER(NP); else DWH_WAIT_BARRIER(0);
+    if (nslab > 2) DWH_WAIT_BARRIER(2); else if (nslab > 1) DWH_WAIT_BARRIER(1); else DWH_WAIT_BARRIER(0);
     int cur = 0;
     for (int sidx = 0; sidx < nslab; ++sidx) {
         const int base = r0 + sidx * RS;
@@ -263,30 +292,36 @@ __global__ __launch_bounds__(512) void dw_h_kernel(DwSeg s, const int* count, in
         if ((sidx % MS) == ms) {                                   // wave-uniform
             const float* sY = lds + cur * slab;
             const float* sX = sY + RS * N;
-            // fragments: rows 8h .. 8h+7 of the slab, column = this lane's output(s) / input(s)
-            AV av[8];
-            float bv[KT][8];
+            // fragments: rows 8h .. 8h+7 of the slab, column = this lane's output(s) / input(s).  The operands are
+            // split words (hi | lo << 16): a fragment is 8 half-words picked from 8 rows, i.e. 4 packs per part.
+            typedef typename VecU<VN>::T UV;
+            const unsigned* wY = reinterpret_cast<const unsigned*>(sY);
+            const unsigned* wX = reinterpret_cast<const unsigned*>(sX);
+            UV av[8];
+            unsigned bv[KT][8];
+            const bool tail = base + RS > r1;                      // only the chunk's last slab can hold rows past r1
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int row = 8 * h + j;
-                av[j] = *reinterpret_cast<const AV*>(sY + row * N + nbase + VN * r);
-                if (base + row >= r1) av[j] = AV(0.f);
+                av[j] = *reinterpret_cast<const UV*>(wY + row * N + nbase + VN * r);
+                if (tail && base + row >= r1) av[j] = UV(0u);
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) bv[kt][j] = sX[row * K + kbase + 32 * kt + r];
+                for (int kt = 0; kt < KT; ++kt) bv[kt][j] = wX[row * K + kbase + 32 * kt + r];
             }
             h8 ah[VN], al[VN], bh[KT], bl[KT];
 #pragma unroll
-            for (int t = 0; t < VN; ++t)
+            for (int t = 0; t < VN; ++t) {
+                unsigned w[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float x = vget<VN>(av[j], t);
-                    bsum[t] += x;
-                    _Float16 a, b; mcn_split(x * sg, a, b); ah[t][j] = a; al[t][j] = b;
+                for (int j = 0; j < 8; ++j) w[j] = uget<VN>(av[j], t);
+                mcn_frag_from_words(w, ah[t], al[t]);
+                if (s.db && kbase == 0) {                           // bias gradient = column sums of dY (still scaled by sg)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum[t] += mcn_unword(w[j], 1.0f);
                 }
+            }
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { _Float16 a, b; mcn_split(bv[kt][j] * MCN_SX, a, b); bh[kt][j] = a; bl[kt][j] = b; }
+            for (int kt = 0; kt < KT; ++kt) mcn_frag_from_words(bv[kt], bh[kt], bl[kt]);
 #pragma unroll
             for (int t = 0; t < VN; ++t)
 #pragma unroll
@@ -298,10 +333,11 @@ __global__ __launch_bounds__(512) void dw_h_kernel(DwSeg s, const int* count, in
         }
         // everyone is done reading `cur`; the next slab has landed for every wave (2 younger slabs may be in flight)
         const int left = nslab - 1 - sidx;       // slabs after this one
-        if (left >= 3) DWH_WAIT_BARRIER(2 * NP); else if (left == 2) DWH_WAIT_BARRIER(NP); else DWH_WAIT_BARRIER(0);
+        if (left >= 3) DWH_WAIT_BARRIER(2); else if (left == 2) DWH_WAIT_BARRIER(1); else DWH_WAIT_BARRIER(0);
         cur = (cur + 1) & 3;
     }
 #undef DWH_WAIT_BARRIER
+#undef DWH_WAIT_ASM
     const float inv = 1.0f / (sg * MCN_SX);
 #pragma unroll
     for (int t = 0; t < VN; ++t)
@@ -317,7 +353,7 @@ __global__ __launch_bounds__(512) void dw_h_kernel(DwSeg s, const int* count, in
     if (s.db && kbase == 0) {
 #pragma unroll
         for (int t = 0; t < VN; ++t) {
-            const float b = bsum[t] + __shfl_xor(bsum[t], 32);
+            const float b = (bsum[t] + __shfl_xor(bsum[t], 32)) * (1.0f / sg);
             const int n = nbase + VN * r + t;
             if (h == 0 && n >= s.n_lo && n < s.n_real) atomicAdd(s.db + (n - s.n_lo), b);
         }

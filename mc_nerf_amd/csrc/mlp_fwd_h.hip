@@ -1,8 +1,8 @@
 // Fused NeRF MLP forward, split-f16 precision mode ("f16x3", see mcnerf_h.h): same structure, tile geometry
 // and outputs as mlp_fwd.hip, but every GEMM runs as three v_mfma_f32_32x32x16_f16 per product on split
 // operands (packed split weights from L2, split activations in LDS) with fp32 accumulation, bias, ReLU and
-// epilogues.  Saved activations / masks / encodings stay fp32 / identical in format, so the backward and
-// weight-gradient kernels are interchangeable between the two precision modes.
+// epilogues.  Saved activations and encodings are written as SPLIT WORDS (hi | lo << 16, scaled by MCN_SX,
+// mcnerf_h.h) in the fp32 workspaces' layout: the split-f16 weight-gradient kernel consumes them directly.
 #include "mcnerf_h.h"
 #include "mcnerf_kernels.h"
 
@@ -32,7 +32,7 @@ __device__ __forceinline__ void write_encoding_h(_Float16* Xh, _Float16* Xl, con
         mcn_split(v * MCN_SX, hi, lo);
         const int o = mcn_hoff<XW>(m, ch >> 3) + (ch & 7);
         Xh[o] = hi; Xl[o] = lo;
-        if (SAVE_ENC && row0 + m < total) enc_save[(size_t)(row0 + m) * MCN_ENCP + ch] = v;
+        if (SAVE_ENC && row0 + m < total) reinterpret_cast<unsigned*>(enc_save)[(size_t)(row0 + m) * MCN_ENCP + ch] = mcn_word(hi, lo);
     };
     for (int it = tid; it < MT * 30; it += nthreads) {
         const int m = it / 30, cf = it - m * 30;
@@ -85,8 +85,10 @@ __device__ __forceinline__ void layer_epilogue_h(f32x16 (&acc)[NI][MI], const fl
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dot[mi] = fmaf(v[e], ww[e], dot[mi]);
                 }
-                if (TO_LDS) mcn_store_split4<(WIDTH > 64 ? WIDTH : 64)>(Xh, Xl, m, n4, v);
-                if (SAVE && ok) *reinterpret_cast<f32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = v;
+                u32x4 w;
+                if (TO_LDS) w = mcn_store_split4<(WIDTH > 64 ? WIDTH : 64)>(Xh, Xl, m, n4, v);
+                else if (SAVE) w = mcn_words4(v, MCN_SX);
+                if (SAVE && ok) *reinterpret_cast<u32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = w;     // split words
             }
             if (SAVE) {
                 const unsigned w = bits | (unsigned)__shfl_xor((int)bits, 32);

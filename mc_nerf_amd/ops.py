@@ -263,3 +263,15 @@ def gather_gt(image_u8: Tensor, pix: Tensor) -> Tensor:
     out = torch.empty(n, 3, dtype=torch.float32, device=pix.device)
     _lib.call("mcnerf_gather_gt", _p(image_u8, torch.uint8), int(image_u8.shape[-1]), _p(pix, torch.int64), n, _p(out), _stream())
     return out
+
+
+SPLIT_SCALE_X = 8.0      # MCN_SX of csrc/mcnerf_h.h
+
+
+def decode_split_words(t: Tensor, scale: float = SPLIT_SCALE_X) -> Tensor:
+    """Workspaces written by the f16x3 kernels hold one `hi | lo << 16` word per value (mcnerf_h.h); this returns
+    the fp32 values (hi + lo) / scale.  Debug / test helper: the kernels consume the words directly."""
+    w = t.view(torch.int32)
+    hi = (w & 0xFFFF).to(torch.int16).view(torch.float16).float()
+    lo = ((w >> 16) & 0xFFFF).to(torch.int16).view(torch.float16).float()
+    return (hi + lo) / scale

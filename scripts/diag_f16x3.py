@@ -27,9 +27,10 @@ for width, nc in ((32, O.NetCfg(4, 32, (2,))), (64, O.NetCfg(8, 64, (4,))), (128
         ops.mlp_fwd(net, flat, packed, o.to(dev), d.to(dev), zg.to(dev), jit.reshape(-1).to(dev).contiguous(),
                     torch.ones(10, device=dev), out, save=save, precision=prec)
         torch.cuda.synchronize()
-        act = save.act.view(nc.depth + 2, save.capacity, width).cpu()
+        dec = (lambda t_: t_) if prec == 'f32' else ops.decode_split_words
+        act = dec(save.act).view(nc.depth + 2, save.capacity, width).cpu()
         errs = [float((act[l] - h).abs().max()) for l, h in enumerate(hidden)]
-        res[prec] = (float((out.view(-1, 4).cpu() - ref).abs().max()), max(errs), float((save.enc.view(-1, 64)[:, :63].cpu() - O.embed(xyz, 1.0, cfg)).abs().max()))
+        res[prec] = (float((out.view(-1, 4).cpu() - ref).abs().max()), max(errs), float((dec(save.enc).view(-1, 64)[:, :63].cpu() - O.embed(xyz, 1.0, cfg)).abs().max()))
     print(f"W={width}: out/hidden/enc max err  f32 {res['f32'][0]:.2e}/{res['f32'][1]:.2e}/{res['f32'][2]:.1e}   f16x3 {res['f16x3'][0]:.2e}/{res['f16x3'][1]:.2e}/{res['f16x3'][2]:.1e}")
 # speed at scale (fine net, dense mode, save)
 nc = O.NetCfg(8, 256, (4,)); net = ops.Net(8, 256, 4)
