@@ -226,6 +226,63 @@ def test_mlp_fwd_bwd_indexed(gpu_device, width, precision):
         assert e < tol, f"{name}: {e} (tol {tol})"
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("width", [32, 64, 128, 256])
+def test_mlp_dw_at_scale(gpu_device, width, precision):
+    """The persistent dW kernels over ~0.4 M rows (thousands of slabs per workgroup, all ring/DMA paths busy) against
+    a torch fp64 GEMM of the very operands they read (the saved activations and dY written by the HIP fwd/bwd)."""
+    ops = _ops()
+    dev = gpu_device
+    nc = NETS[width]
+    net = net_of(nc)
+    D, W, skip = nc.depth, nc.width, nc.skips[0]
+    N, S = 3001, 128                     # ragged row count
+    rows = N * S
+    p = O.init_params(nc, 300 + width)
+    flat = flat_params(nc, p, dev)
+    packed = ops.pack_weights(net, flat, precision=precision)
+    d, o = make_rays(N, 77)
+    od, dd, zd = o.to(dev), d.to(dev), torch.linspace(1, 8, S, device=dev)
+    bw = torch.ones(10, device=dev)
+    out = torch.empty(N, S, 4, device=dev)
+    save = ops.alloc_save(net, rows, dev)
+    ops.mlp_fwd(net, flat, packed, od, dd, zd, None, bw, out, save=save, precision=precision)
+    d_out = torch.randn(N, S, 4, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 1e-3
+    gmax = d_out.abs().max().reshape(1).view(torch.int32)
+    dy, dsh = torch.empty_like(save.act), torch.empty_like(save.sh)
+    d_o, d_d = torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev)
+    ops.mlp_bwd(net, flat, packed, od, dd, zd, None, bw, out, d_out, save, dy, dsh, d_o, d_d, precision=precision, gmax=gmax)
+    grads = torch.zeros_like(flat)
+    ops.mlp_dw(net, save, dy, dsh, grads, rows, precision=precision, gmax=gmax)
+    torch.cuda.synchronize()
+    if precision == "f32":
+        act, enc, dyv, dshv = save.act, save.enc, dy, dsh
+    else:
+        sg = 2.0 ** (4 - math.ceil(math.log2(float(d_out.abs().max()))))
+        act, enc = ops.decode_split_words(save.act), ops.decode_split_words(save.enc)
+        dyv, dshv = ops.decode_split_words(dy, sg), ops.decode_split_words(dsh, sg)
+    act = act.view(D + 2, rows, W).double()
+    dyv = dyv.view(D + 2, rows, W).double()
+    enc = enc.view(rows, 64)[:, :63].double()
+    dshv = dshv.view(rows, 32).double()
+    ref = {}
+    for l in range(D):
+        x = enc if l == 0 else (torch.cat([enc, act[l - 1]], 1) if l == skip else act[l - 1])
+        ref[f"xyz_encoding_{l + 1}.0.weight"] = dyv[l].t() @ x
+        ref[f"xyz_encoding_{l + 1}.0.bias"] = dyv[l].sum(0)
+    ref["sigma.0.weight"], ref["sigma.0.bias"] = dyv[D].t() @ act[D - 1], dyv[D].sum(0)
+    ref["sh.0.weight"], ref["sh.0.bias"] = dyv[D + 1].t() @ act[D - 1], dyv[D + 1].sum(0)
+    ref["sh.2.weight"], ref["sh.2.bias"] = dshv[:, :27].t() @ act[D + 1], dshv[:, :27].sum(0)
+    ref["sigma.2.weight"], ref["sigma.2.bias"] = dshv[:, 27:28].t() @ act[D], dshv[:, 27:28].sum(0)
+    for off, shp, name in zip(ops.param_offsets(net), net.shapes(), net.names()):
+        n = int(np.prod(shp))
+        got = grads[off:off + n].view(shp).double()
+        want = ref[name].view(shp)
+        scale = float(want.abs().max())
+        err = float((got - want).abs().max())
+        assert math.isfinite(err) and err <= 2e-5 * max(scale, 1e-12) + 1e-9, f"{name}: err {err:.3e} scale {scale:.3e}"
+
+
 def test_raygen(gpu_device):
     ops = _ops()
     dev = gpu_device
