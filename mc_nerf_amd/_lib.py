@@ -13,7 +13,8 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcnerf.so")
+# MCNERF_LIB selects another build of the SAME library (kernel ablation / tuning variants, scripts/ablate.sh)
+LIB_PATH = os.environ.get("MCNERF_LIB") or os.path.join(_HERE, "libmcnerf.so")
 ABI_VERSION = 1
 
 _P = c_void_p

@@ -21,9 +21,12 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, extra_flags=(), tag=""):
+    """tag / extra_flags build a VARIANT (libmcnerf_<tag>.so with extra -D flags) for kernel ablations; the
+    product library is the untagged one."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + ("_" + tag if tag else ""))
+    out = os.path.join(HERE, f"libmcnerf_{tag}.so") if tag else OUT
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     jobs = []
@@ -34,7 +37,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 
@@ -47,15 +50,16 @@ def build(force=False, verbose=True):
             if verbose:
                 print(f"[mc_nerf_amd.build] compiled {os.path.basename(src)}")
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if jobs or not os.path.exists(OUT):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if jobs or not os.path.exists(out):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed\n" + r.stdout + r.stderr)
         if verbose:
-            print(f"[mc_nerf_amd.build] linked {OUT}")
-    return OUT
+            print(f"[mc_nerf_amd.build] linked {out}")
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    tag = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), "")
+    build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a.startswith("-D")], tag=tag)

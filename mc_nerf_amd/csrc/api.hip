@@ -2,6 +2,11 @@
 // kernel is enqueued on the caller's stream, nothing here synchronises or allocates.
 #include "../../include/mcnerf.h"
 #include "mcnerf_kernels.h"
+#ifdef ABL_ALIAS     // (ablation build only: every workspace slot aliases slot 0 = same bytes moved, 1/10 of the footprint)
+#define MCN_ACT_STRIDE(capacity, width) ((size_t)0)
+#else
+#define MCN_ACT_STRIDE(capacity, width) ((size_t)(capacity) * (width))
+#endif
 #include <stdio.h>
 #include <string.h>
 
@@ -88,7 +93,7 @@ int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const fl
     a.lay = mcn_make_layout(depth, width, skip);
     a.params = params; a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter;
     a.barf_w = barf_w; a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
-    a.out = out; a.act_save = act_save; a.act_stride = (size_t)capacity * width; a.enc_save = enc_save; a.sh_save = sh_save; a.mask_save = mask_save;
+    a.out = out; a.act_save = act_save; a.act_stride = MCN_ACT_STRIDE(capacity, width); a.enc_save = enc_save; a.sh_save = sh_save; a.mask_save = mask_save;
     return check("mcnerf_mlp_fwd", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
 }
 
@@ -110,7 +115,7 @@ int mcnerf_mlp_fwd_f16x3(int depth, int width, int skip, const float* params, co
     a.lay = mcn_make_layout(depth, width, skip);
     a.params = params; a.packed = (const float*)packed16; a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter;
     a.barf_w = barf_w; a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
-    a.out = out; a.act_save = act_save; a.act_stride = (size_t)capacity * width; a.enc_save = enc_save; a.sh_save = sh_save; a.mask_save = mask_save;
+    a.out = out; a.act_save = act_save; a.act_stride = MCN_ACT_STRIDE(capacity, width); a.enc_save = enc_save; a.sh_save = sh_save; a.mask_save = mask_save;
     return check("mcnerf_mlp_fwd_f16x3", mcn_launch_mlp_fwd_h(a, (hipStream_t)stream));
 }
 
@@ -129,7 +134,7 @@ int mcnerf_mlp_bwd(int depth, int width, int skip, const float* params, const fl
     a.lay = mcn_make_layout(depth, width, skip);
     a.params = params; a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter;
     a.barf_w = barf_w; a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
-    a.out = out; a.d_out = d_out; a.mask_save = mask_save; a.act_stride = (size_t)capacity * width;
+    a.out = out; a.d_out = d_out; a.mask_save = mask_save; a.act_stride = MCN_ACT_STRIDE(capacity, width);
     a.enc_save = enc_save; a.sh_save = sh_save; a.dy_save = dy_save; a.dsh_save = dsh_save;
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d; a.gmax_bits = nullptr;
     return check("mcnerf_mlp_bwd", mcn_launch_mlp_bwd(a, (hipStream_t)stream));
@@ -150,7 +155,7 @@ int mcnerf_mlp_bwd_f16x3(int depth, int width, int skip, const float* params, co
     a.lay = mcn_make_layout(depth, width, skip);
     a.params = params; a.packed = (const float*)packed16; a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter;
     a.barf_w = barf_w; a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
-    a.out = out; a.d_out = d_out; a.mask_save = mask_save; a.act_stride = (size_t)capacity * width;
+    a.out = out; a.d_out = d_out; a.mask_save = mask_save; a.act_stride = MCN_ACT_STRIDE(capacity, width);
     a.enc_save = enc_save; a.sh_save = sh_save; a.dy_save = dy_save; a.dsh_save = dsh_save;
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d; a.gmax_bits = gmax_bits;
     return check("mcnerf_mlp_bwd_f16x3", mcn_launch_mlp_bwd_h(a, (hipStream_t)stream));
@@ -164,7 +169,7 @@ int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows
     McnDwArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
     a.count = count; a.rows = rows; a.act_save = act_save; a.enc_save = enc_save; a.dy_save = dy_save;
-    a.dsh_save = dsh_save; a.act_stride = (size_t)capacity * width; a.grads = grads; a.split16 = false; a.gmax_bits = nullptr;
+    a.dsh_save = dsh_save; a.act_stride = MCN_ACT_STRIDE(capacity, width); a.grads = grads; a.split16 = false; a.gmax_bits = nullptr;
     return check("mcnerf_mlp_dw", mcn_launch_dw(a, (hipStream_t)stream));
 }
 
@@ -176,7 +181,7 @@ int mcnerf_mlp_dw_f16x3(int depth, int width, int skip, const int32_t* count, in
     McnDwArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
     a.count = count; a.rows = rows; a.act_save = act_save; a.enc_save = enc_save; a.dy_save = dy_save;
-    a.dsh_save = dsh_save; a.act_stride = (size_t)capacity * width; a.grads = grads; a.split16 = true; a.gmax_bits = gmax_bits;
+    a.dsh_save = dsh_save; a.act_stride = MCN_ACT_STRIDE(capacity, width); a.grads = grads; a.split16 = true; a.gmax_bits = gmax_bits;
     return check("mcnerf_mlp_dw_f16x3", mcn_launch_dw(a, (hipStream_t)stream));
 }
 

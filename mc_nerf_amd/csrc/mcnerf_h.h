@@ -15,6 +15,12 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
+#ifndef MCN_GROUPS          // tiles (wave groups) per workgroup of the split-f16 forward / backward chains: 1 | 2 (ping-pong)
+#define MCN_GROUPS 1
+#endif
+#ifndef MCN_COPY_MODE
+#define MCN_COPY_MODE 2
+#endif
 #define MCN_SW 256.0f
 #define MCN_SX 8.0f
 
@@ -33,9 +39,16 @@ __device__ __forceinline__ int mcn_hoff(int m, int c) {
 
 // acc[ni][mi] += W-fragment x X-fragment over KS16 k-steps of 16, three MFMAs per product.
 //   P : packed split weights for this wave's first n-tile, h8 units: [ni][KS16][2][64 lanes]
-template <int XW, int NI, int MI>
+struct McnNoSide { __device__ __forceinline__ void operator()(int) const {} };
+
+//   side(ks) : optional per-k-step side job issued with the prefetches (used to trickle the previous layer's
+//              workspace rows out to HBM while the MFMAs run, instead of one burst per layer)
+//   pre()    : optional job issued once, AFTER the first two k-steps' weight loads are in flight (stores issued
+//              there do not sit in front of those loads in the in-order vmcnt queue)
+struct McnNoPre { __device__ __forceinline__ void operator()() const {} };
+template <int XW, int NI, int MI, class Side = McnNoSide, class Pre = McnNoPre>
 __device__ __forceinline__ void mcn_gemm_seg_h(f32x16 (&acc)[NI][MI], const _Float16* Xh, const _Float16* Xl, int mrow0,
-                                               int kchunk0, int KS16, const h8* __restrict__ P, int lane) {
+                                               int kchunk0, int KS16, const h8* __restrict__ P, int lane, Side side = Side(), Pre pre = Pre()) {
     const int r = lane & 31, h = lane >> 5;
     constexpr int SWZ = (XW / 8 - 1) < 15 ? (XW / 8 - 1) : 15;
     const int sw = (mrow0 + r) & SWZ;
@@ -56,6 +69,9 @@ __device__ __forceinline__ void mcn_gemm_seg_h(f32x16 (&acc)[NI][MI], const _Flo
         bnh[mi] = *reinterpret_cast<const h8*>(Xh + o);
         bnl[mi] = *reinterpret_cast<const h8*>(Xl + o);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    pre();
+    __builtin_amdgcn_sched_barrier(0);
     for (int ks = 0; ks < KS16; ++ks) {
         h8 ach[NI], acl[NI], bh[MI], bl[MI];
 #pragma unroll
@@ -64,8 +80,10 @@ __device__ __forceinline__ void mcn_gemm_seg_h(f32x16 (&acc)[NI][MI], const _Flo
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) { a1h[ni] = pa[ni][256]; a1l[ni] = pa[ni][320]; }
         }
+#ifndef ABL_W        // (ablation: keep re-reading the same fragments = L1 hits)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) pa[ni] += 128;
+#endif
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) { bh[mi] = bnh[mi]; bl[mi] = bnl[mi]; }
         if (ks + 1 < KS16) {
@@ -76,15 +94,31 @@ __device__ __forceinline__ void mcn_gemm_seg_h(f32x16 (&acc)[NI][MI], const _Flo
                 bnl[mi] = *reinterpret_cast<const h8*>(Xl + o);
             }
         }
+        side(ks);
         __builtin_amdgcn_sched_barrier(0);       // keep the prefetches above this step's MFMAs
+#if defined(MCN_MFMA_ORDER) && MCN_MFMA_ORDER == 1
+        // the three partial products of one accumulator issued NI*MI MFMAs apart (no back-to-back dependent MFMAs)
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(part == 2 ? acl[ni] : ach[ni], part == 1 ? bl[mi] : bh[mi], acc[ni][mi], 0, 0, 0);
+#else
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ach[ni], bh[mi], acc[ni][mi], 0, 0, 0);
+#ifndef ABL_MFMA1   // (ablation: one MFMA per product, the lo operands folded in by cheap VALU so that their loads stay)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ach[ni], bl[mi], acc[ni][mi], 0, 0, 0);
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(acl[ni], bh[mi], acc[ni][mi], 0, 0, 0);
+#else
+                acc[ni][mi][0] += (float)bl[mi][0] + (float)acl[ni][0];
+#endif
             }
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -113,6 +147,66 @@ __device__ __forceinline__ u32x4 mcn_store_split4(_Float16* Xh, _Float16* Xl, in
     *reinterpret_cast<h4*>(Xh + o) = hi;
     *reinterpret_cast<h4*>(Xl + o) = lo;
     return w;
+}
+// Cooperative, row-coalesced copy of the split LDS tile (columns 0 .. COLS-1 of every row) to a split-word
+// workspace [rows][COLS]: one wave instruction stores whole contiguous rows (a lane-local store out of the MFMA
+// accumulator layout would scatter 32-byte pieces over 32 rows per instruction).  The copy is MT*COLS/4/NT
+// "trips" per thread; mcn_copy_tile_step does the share of k-step ks of a KS-step GEMM.
+template <int MT, int XW, int COLS, int NT>
+__device__ __forceinline__ void mcn_copy_tile_trip(const _Float16* Xh, const _Float16* Xl, float* __restrict__ dst,
+                                                   long long row0, long long total, int tid, int k) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    constexpr int C4 = COLS / 4;
+    const int it = tid + k * NT;
+    const int m = it / C4, n4 = 4 * (it - m * C4);
+    const int o = mcn_hoff<XW>(m, n4 >> 3) + (n4 & 7);
+    const u2 H = *reinterpret_cast<const u2*>(Xh + o);
+    const u2 L = *reinterpret_cast<const u2*>(Xl + o);
+    u32x4 w;
+    w[0] = __builtin_amdgcn_perm(L[0], H[0], 0x05040100u);
+    w[1] = __builtin_amdgcn_perm(L[0], H[0], 0x07060302u);
+    w[2] = __builtin_amdgcn_perm(L[1], H[1], 0x05040100u);
+    w[3] = __builtin_amdgcn_perm(L[1], H[1], 0x07060302u);
+#ifdef ABL_NOSTORE   // (ablation: LDS reads and packs only)
+    if (total < 0) *reinterpret_cast<u32x4*>(dst + (size_t)(row0 + m) * COLS + n4) = w;
+#elif defined(ABL_NOHBM)     // (ablation: every workgroup writes the same 64 rows = stores issue but stay in L2)
+    if (row0 + m < total) *reinterpret_cast<u32x4*>(dst + (size_t)(m) * COLS + n4) = w;
+#elif defined(ABL_NT)
+    if (row0 + m < total) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst + (size_t)(row0 + m) * COLS + n4));
+#else
+    if (row0 + m < total) *reinterpret_cast<u32x4*>(dst + (size_t)(row0 + m) * COLS + n4) = w;
+#endif
+}
+template <int MT, int XW, int COLS, int NT>
+__device__ __forceinline__ void mcn_copy_tile_words(const _Float16* Xh, const _Float16* Xl, float* __restrict__ dst,
+                                                    long long row0, long long total, int tid) {
+    constexpr int TRIPS = MT * (COLS / 4) / NT, U = TRIPS < 4 ? TRIPS : 4;      // groups of U keep the register footprint small
+    static_assert((MT * (COLS / 4)) % NT == 0 && TRIPS % U == 0, "tile copy shape");
+#pragma unroll 1
+    for (int k0 = 0; k0 < TRIPS; k0 += U)
+#pragma unroll
+        for (int k = k0; k < k0 + U; ++k) mcn_copy_tile_trip<MT, XW, COLS, NT>(Xh, Xl, dst, row0, total, tid, k);
+}
+template <int MT, int XW, int COLS, int NT, int KS>
+__device__ __forceinline__ void mcn_copy_tile_step(const _Float16* Xh, const _Float16* Xl, float* __restrict__ dst,
+                                                   long long row0, long long total, int tid, int ks) {
+    [[maybe_unused]] constexpr int TRIPS = MT * (COLS / 4) / NT;
+    static_assert((MT * (COLS / 4)) % NT == 0, "tile copy shape");
+#if MCN_COPY_MODE == 0          // one row group per k-step
+    constexpr int TPS = (TRIPS + KS - 1) / KS;
+#pragma unroll
+    for (int j = 0; j < TPS; ++j) {
+        const int k = ks * TPS + j;
+        if (k < TRIPS) mcn_copy_tile_trip<MT, XW, COLS, NT>(Xh, Xl, dst, row0, total, tid, k);
+    }
+#elif MCN_COPY_MODE == 1        // everything in the last two k-steps (after the GEMM's last weight load was issued)
+    constexpr int HALF = (TRIPS + 1) / 2;
+    if (ks >= KS - 2 || KS < 2) {
+        const int k0 = (KS < 2 || ks == KS - 2) ? 0 : HALF, k1 = (KS < 2) ? TRIPS : (ks == KS - 2 ? HALF : TRIPS);
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) mcn_copy_tile_trip<MT, XW, COLS, NT>(Xh, Xl, dst, row0, total, tid, k);
+    }
+#endif                          // (mode 2: the caller copies the whole tile before the GEMM, nothing here)
 }
 // split words of 4 values without touching LDS
 __device__ __forceinline__ u32x4 mcn_words4(const f32x4& v, float scale) {

@@ -29,10 +29,11 @@ __device__ __forceinline__ u32x4 store_split4_s(_Float16* Xh, _Float16* Xl, int 
     return mcn_store_split4<XW>(Xh, Xl, m, n4, v, sg);
 }
 
-// acc (scaled gradient wrt a post-ReLU activation) * inv -> masked by the forward's ReLU bit mask -> dy_save
-// (fp32, unscaled) + LDS tile (split f16, scaled by sg).  Mask words are read with unconditional loads.
+// acc (scaled gradient wrt a post-ReLU activation) * inv -> masked by the forward's ReLU bit mask -> LDS tile
+// (split f16, scaled by sg); the caller then copies the tile rows to dy_save (mcn_copy_tile_words, row-coalesced).
+// Mask words are read with unconditional loads.
 template <int WIDTH, int NI, int MI>
-__device__ __forceinline__ void mask_store_h(f32x16 (&acc)[NI][MI], const unsigned int* __restrict__ msave, float* __restrict__ dysave,
+__device__ __forceinline__ void mask_store_h(f32x16 (&acc)[NI][MI], const unsigned int* __restrict__ msave,
                                              _Float16* Xh, _Float16* Xl, float inv, float sg, int mrow0, int ncol0,
                                              long long row0, long long total, int lane) {
     constexpr int XW = WIDTH > 64 ? WIDTH : 64;
@@ -59,20 +60,24 @@ __device__ __forceinline__ void mask_store_h(f32x16 (&acc)[NI][MI], const unsign
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ((w >> e) & 1u) ? acc[ni][mi][4 * q + e] * inv : 0.f;
-                const u32x4 w4 = store_split4_s<XW>(Xh, Xl, m, k4, v, sg);
-                if (ok) *reinterpret_cast<u32x4*>(dysave + (size_t)(row0 + m) * WIDTH + k4) = w4;      // split words, scaled by sg
+                store_split4_s<XW>(Xh, Xl, m, k4, v, sg);
             }
         }
 }
 
+// Two tiles per workgroup in ping-pong (see mlp_fwd_h.hip): group 0 = waves 0-3, group 1 = waves 4-7, own LDS
+// regions, workgroup-wide barriers, group 1 one barrier behind, so that one group's MFMA phase overlaps the
+// other's mask / split / write-back phase on every SIMD.
 template <int WIDTH>
-__global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) void mlp_bwd_h_kernel(McnMlpBwdArgs a) {
+__global__ __launch_bounds__(MCN_GROUPS * McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2 / MCN_GROUPS) void mlp_bwd_h_kernel(McnMlpBwdArgs a) {
     using G = McnGeom<WIDTH>;
     using SM = BwdSmemH<WIDTH>;
     constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN, NT = SM::NT, WAVES = NT / 64;
     constexpr int NSH = WIDTH / 16;           // reduction steps (of 16) over a hidden-wide dY
     constexpr int W4 = WIDTH / 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int grp = MCN_GROUPS > 1 ? threadIdx.x / NT : 0;                     // 0 | 1 (wave-uniform)
+    float* smem = smem_all + grp * SM::total;
     _Float16* Xh = reinterpret_cast<_Float16*>(smem + SM::oX);
     _Float16* Xl = Xh + MT * XW;
     float* Xf = smem + SM::oX;                // fp32 view of the same region for the final encoding-gradient stage
@@ -82,17 +87,18 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     int* sray = reinterpret_cast<int*>(smem + SM::oAddr);
     float* sz = smem + SM::oZ;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x - grp * NT, lane = tid & 63, wave = tid >> 6;      // group-local ids
     const int wn = wave % WN, wm = wave / WN;
     const int mrow0 = wm * MI * 32, ncol0 = wn * NI * 32;
     const long long total = a.count ? (long long)min(*a.count, a.max_rows) : (long long)a.n_rays * a.S;
-    const long long row0 = (long long)blockIdx.x * MT;
-    if (row0 >= total) return;
+    const long long row0 = ((long long)blockIdx.x * MCN_GROUPS + grp) * MT;
+    if (row0 >= total) return;            // (a finished wave no longer counts at the workgroup's barriers)
     const McnLayout& L = a.lay;
     const int D = L.depth;
     const float* __restrict__ prm = a.params;
     const h8* __restrict__ pk = reinterpret_cast<const h8*>(a.packed);     // split-f16 transposed packed weights
     const size_t AS = a.act_stride;
+    if (MCN_GROUPS > 1 && grp == 1) __syncthreads();        // phase offset: group 1 runs one barrier behind group 0
     // gradient scale: a power of two that puts max|d_out| of this launch near 2^4 in f16 (4096x headroom below
     // the f16 maximum for growth through the layers, ~2^-18 of the maximum before f16 subnormals start)
     const float gmax = a.gmax_bits ? __uint_as_float(*a.gmax_bits) : 1.f;
@@ -155,11 +161,17 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     mcn_zero<NI, MI>(acc);
     mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, MCN_NSHP / 16, pk + (L.bC2 >> 2) + (wn * NI) * (MCN_NSHP / 16) * 128, lane);
     __syncthreads();
-    mask_store_h<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(D + 1) * (AS / 32), a.dy_save + (size_t)(D + 1) * AS, Xh, Xl, inv, sg, mrow0, ncol0, row0, total, lane);
+    mask_store_h<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(D + 1) * (AS / 32), Xh, Xl, inv, sg, mrow0, ncol0, row0, total, lane);
     __syncthreads();
-    // ---- sh.0^T and sigma.0^T both feed d h_{D-1}
+    // ---- sh.0^T and sigma.0^T both feed d h_{D-1}.  (Every dY tile is trickled out to dy_save, row-coalesced,
+    //      by the GEMM that reads it: one row group per k-step.)
     mcn_zero<NI, MI>(acc);
-    mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, NSH, pk + (L.bC1 >> 2) + (wn * NI) * NSH * 128, lane);
+    {
+        float* const dst = a.dy_save + (size_t)(D + 1) * AS;
+        mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, NSH, pk + (L.bC1 >> 2) + (wn * NI) * NSH * 128, lane,
+            [=](int ks) { mcn_copy_tile_step<MT, XW, WIDTH, NT, NSH>(Xh, Xl, dst, row0, total, tid, ks); },
+            [=]() { if (MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, dst, row0, total, tid); });
+    }
     __syncthreads();
     {   // dY of sigma.0 = d sigma * w_sigma2 masked by hs > 0 (outer product, no GEMM)
         const unsigned int* hm = a.mask_save + (size_t)D * (AS / 32);
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     __syncthreads();
     mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, NSH, pk + (L.bS1 >> 2) + (wn * NI) * NSH * 128, lane);
     __syncthreads();
-    mask_store_h<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(D - 1) * (AS / 32), a.dy_save + (size_t)(D - 1) * AS, Xh, Xl, inv, sg, mrow0, ncol0, row0, total, lane);
+    mask_store_h<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(D - 1) * (AS / 32), Xh, Xl, inv, sg, mrow0, ncol0, row0, total, lane);
     __syncthreads();
 
     // ---- trunk, last layer to first.  X holds dY_l; the encoded-input gradient accumulates in denc.
@@ -205,11 +217,17 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
                 if (t < ENC_TILES) mcn_gemm_seg_h<XW, 1, 1>(denc2, Xh, Xl, (t >> 1) * 32, 0, NSH, pe + (t & 1) * NSH * 128, lane);
             }
         }
-        if (l == 0) break;
+        float* const dst = a.dy_save + (size_t)l * AS;           // X holds dY_l
+        if (l == 0) {
+            mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, dst, row0, total, tid);
+            break;
+        }
         mcn_zero<NI, MI>(acc);
-        mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, NSH, pk + (L.bH[l] >> 2) + (wn * NI) * NSH * 128, lane);
+        mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, NSH, pk + (L.bH[l] >> 2) + (wn * NI) * NSH * 128, lane,
+            [=](int ks) { mcn_copy_tile_step<MT, XW, WIDTH, NT, NSH>(Xh, Xl, dst, row0, total, tid, ks); },
+            [=]() { if (MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, dst, row0, total, tid); });
         __syncthreads();
-        mask_store_h<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(l - 1) * (AS / 32), a.dy_save + (size_t)(l - 1) * AS, Xh, Xl, inv, sg, mrow0, ncol0, row0, total, lane);
+        mask_store_h<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(l - 1) * (AS / 32), Xh, Xl, inv, sg, mrow0, ncol0, row0, total, lane);
         __syncthreads();
     }
     __syncthreads();
@@ -275,12 +293,12 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
 template <int WIDTH>
 static hipError_t launch_bwd_h(const McnMlpBwdArgs& a, long long max_rows, hipStream_t st) {
     using SM = BwdSmemH<WIDTH>;
-    const int grid = (int)((max_rows + SM::MT - 1) / SM::MT);
+    const int grid = (int)((max_rows + MCN_GROUPS * SM::MT - 1) / (MCN_GROUPS * SM::MT));      // MCN_GROUPS tiles per workgroup
     if (grid <= 0) return hipSuccess;
     auto kern = mlp_bwd_h_kernel<WIDTH>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MCN_GROUPS * SM::bytes));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(SM::NT), SM::bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MCN_GROUPS * SM::NT), MCN_GROUPS * SM::bytes, st, a);
     return hipGetLastError();
 }
 

@@ -22,17 +22,15 @@ struct FwdSmemH {
     static constexpr size_t bytes = (size_t)total * 4;
 };
 
-// Writes the 63(+1 pad) encoded channels of every tile row into the split LDS tile (and, on the first pass
-// of a training forward, into enc_save as fp32).  Channel order as in mlp_fwd.hip / model/net_block.py:22-33.
-template <int MT, int XW, bool SAVE_ENC>
-__device__ __forceinline__ void write_encoding_h(_Float16* Xh, _Float16* Xl, const float* sxyz, const float* barf_w, int tid, int nthreads,
-                                                 float* enc_save, long long row0, long long total) {
+// Writes the 63(+1 pad) encoded channels of every tile row into the split LDS tile (a training forward then
+// copies the tile rows to enc_save).  Channel order as in mlp_fwd.hip / model/net_block.py:22-33.
+template <int MT, int XW>
+__device__ __forceinline__ void write_encoding_h(_Float16* Xh, _Float16* Xl, const float* sxyz, const float* barf_w, int tid, int nthreads) {
     auto put = [&](int m, int ch, float v) {
         _Float16 hi, lo;
         mcn_split(v * MCN_SX, hi, lo);
         const int o = mcn_hoff<XW>(m, ch >> 3) + (ch & 7);
         Xh[o] = hi; Xl[o] = lo;
-        if (SAVE_ENC && row0 + m < total) reinterpret_cast<unsigned*>(enc_save)[(size_t)(row0 + m) * MCN_ENCP + ch] = mcn_word(hi, lo);
     };
     for (int it = tid; it < MT * 30; it += nthreads) {
         const int m = it / 30, cf = it - m * 30;
@@ -52,7 +50,7 @@ __device__ __forceinline__ void write_encoding_h(_Float16* Xh, _Float16* Xl, con
 
 // Layer epilogue shared by the trunk layers and the two head hidden layers: v = relu(acc + bias);
 //   TO_LDS : write v into the LDS tile (next layer's input)
-//   SAVE   : store v (dW operand) and its 1-bit ReLU mask (backward chain) to the workspaces
+//   SAVE   : store the 1-bit ReLU mask (backward chain) and, unless TO_LDS, v as split words (dW operand)
 //   DOT    : accumulate sum_n v[n] * w2[n] per sample (the 1-wide sigma output layer, lane-local)
 // A lane holds 16 of the 32 columns of its row per tile (the other 16 sit in lane ^ 32), so the mask halves
 // are combined with one cross-lane move.
@@ -88,7 +86,8 @@ __device__ __forceinline__ void layer_epilogue_h(f32x16 (&acc)[NI][MI], const fl
                 u32x4 w;
                 if (TO_LDS) w = mcn_store_split4<(WIDTH > 64 ? WIDTH : 64)>(Xh, Xl, m, n4, v);
                 else if (SAVE) w = mcn_words4(v, MCN_SX);
-                if (SAVE && ok) *reinterpret_cast<u32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = w;     // split words
+                // (layers that go to the LDS tile are saved from there, row-coalesced: mcn_copy_tile_words)
+                if (SAVE && !TO_LDS && ok) *reinterpret_cast<u32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = w;     // split words
             }
             if (SAVE) {
                 const unsigned w = bits | (unsigned)__shfl_xor((int)bits, 32);
@@ -97,14 +96,22 @@ __device__ __forceinline__ void layer_epilogue_h(f32x16 (&acc)[NI][MI], const fl
         }
 }
 
+// Two tiles per workgroup, "ping-pong": waves 0-3 (group 0) and waves 4-7 (group 1) each run the whole per-tile
+// program on their own LDS region, but every barrier is workgroup-wide and group 1 starts one barrier late.  The
+// program alternates MFMA phases (layer GEMMs) and VALU/LDS phases (epilogues) separated by barriers, so the two
+// waves that share a SIMD are held in opposite phases: one feeds the matrix pipe while the other does bias / ReLU /
+// split / LDS write-back, instead of both drifting into lockstep (measured: MFMA and VALU co-executed in only 6 %
+// of the MFMA-busy cycles with two independent workgroups per CU).
 template <int WIDTH, bool SAVE>
-__global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) void mlp_fwd_h_kernel(McnMlpFwdArgs a) {
+__global__ __launch_bounds__(MCN_GROUPS * McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2 / MCN_GROUPS) void mlp_fwd_h_kernel(McnMlpFwdArgs a) {
     using G = McnGeom<WIDTH>;
     using SM = FwdSmemH<WIDTH>;
     constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN, NT = SM::NT, WAVES = NT / 64;
     constexpr int KSH = WIDTH / 16;     // k-steps (of 16) of a hidden segment
     constexpr int KSE = MCN_ENCP / 16;  // ... of the encoded segment
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int grp = MCN_GROUPS > 1 ? threadIdx.x / NT : 0;                     // 0 | 1 (wave-uniform)
+    float* smem = smem_all + grp * SM::total;
     _Float16* Xh = reinterpret_cast<_Float16*>(smem + SM::oX);
     _Float16* Xl = Xh + MT * XW;
     float* sxyz = smem + SM::oXyz;
@@ -113,17 +120,18 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     float* ssh = smem + SM::oSh;
     int* saddr = reinterpret_cast<int*>(smem + SM::oAddr);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x - grp * NT, lane = tid & 63, wave = tid >> 6;      // group-local ids
     const int wn = wave % WN, wm = wave / WN;
     const int r = lane & 31, h = lane >> 5;
     const int mrow0 = wm * MI * 32;
     const int ncol0 = wn * NI * 32;
     const long long total = a.count ? (long long)min(*a.count, a.max_rows) : (long long)a.n_rays * a.S;
-    const long long row0 = (long long)blockIdx.x * MT;
-    if (row0 >= total) return;
+    const long long row0 = ((long long)blockIdx.x * MCN_GROUPS + grp) * MT;
+    if (row0 >= total) return;            // (a finished wave no longer counts at the workgroup's barriers)
     const McnLayout& L = a.lay;
     const float* __restrict__ prm = a.params;
     const h8* __restrict__ pk = reinterpret_cast<const h8*>(a.packed);     // split-f16 packed weights (16-byte units)
+    if (MCN_GROUPS > 1 && grp == 1) __syncthreads();        // phase offset: group 1 runs one barrier behind group 0
 
     // ---- per-sample setup: position, direction, output address
     for (int m = tid; m < MT; m += NT) {
@@ -148,20 +156,28 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
         saddr[m] = addr;
     }
     __syncthreads();
-    write_encoding_h<MT, XW, SAVE>(Xh, Xl, sxyz, a.barf_w, tid, NT, a.enc_save, row0, total);
+    write_encoding_h<MT, XW>(Xh, Xl, sxyz, a.barf_w, tid, NT);
     __syncthreads();
 
     f32x16 acc[NI][MI];
     // ---- trunk
     for (int l = 0; l < L.depth; ++l) {
         mcn_zero<NI, MI>(acc);
+        // a training forward trickles the tile it is reading (encoding / previous layer's output) out to the
+        // workspaces during the GEMM, one row group per k-step
+        float* const prev = SAVE && l > 0 ? a.act_save + (size_t)(l - 1) * a.act_stride : nullptr;
         if (l == 0) {
-            mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSE, pk + (L.fEnc0 >> 2) + (wn * NI) * KSE * 128, lane);
+            float* const encs = a.enc_save;
+            mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSE, pk + (L.fEnc0 >> 2) + (wn * NI) * KSE * 128, lane,
+                [=](int ks) { if (SAVE) mcn_copy_tile_step<MT, XW, MCN_ENCP, NT, KSE>(Xh, Xl, encs, row0, total, tid, ks); },
+                [=]() { if (SAVE && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, MCN_ENCP, NT>(Xh, Xl, encs, row0, total, tid); });
         } else {
-            mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSH, pk + (L.fH[l] >> 2) + (wn * NI) * KSH * 128, lane);
+            mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSH, pk + (L.fH[l] >> 2) + (wn * NI) * KSH * 128, lane,
+                [=](int ks) { if (SAVE) mcn_copy_tile_step<MT, XW, WIDTH, NT, KSH>(Xh, Xl, prev, row0, total, tid, ks); },
+                [=]() { if (SAVE && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, prev, row0, total, tid); });
             if (l == L.skip) {
                 __syncthreads();                       // everyone finished reading h from X
-                write_encoding_h<MT, XW, false>(Xh, Xl, sxyz, a.barf_w, tid, NT, nullptr, row0, total);
+                write_encoding_h<MT, XW>(Xh, Xl, sxyz, a.barf_w, tid, NT);
                 __syncthreads();
                 mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSE, pk + (L.fEncS >> 2) + (wn * NI) * KSE * 128, lane);
             }
@@ -177,7 +193,10 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     // ---- sigma head: hidden layer on MFMA, the 1-wide output layer lane-local on the VALU
     {
         mcn_zero<NI, MI>(acc);
-        mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSH, pk + (L.fS1 >> 2) + (wn * NI) * KSH * 128, lane);
+        float* const prev = SAVE ? a.act_save + (size_t)(L.depth - 1) * a.act_stride : nullptr;
+        mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSH, pk + (L.fS1 >> 2) + (wn * NI) * KSH * 128, lane,
+            [=](int ks) { if (SAVE) mcn_copy_tile_step<MT, XW, WIDTH, NT, KSH>(Xh, Xl, prev, row0, total, tid, ks); },
+            [=]() { if (SAVE && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, prev, row0, total, tid); });
         float s[MI];
         layer_epilogue_h<WIDTH, NI, MI, false, SAVE, true>(acc, prm + L.pBs1, prm + L.pWs2, Xh, Xl,
             SAVE ? a.act_save + (size_t)L.depth * a.act_stride : nullptr,
@@ -199,6 +218,7 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             SAVE ? a.mask_save + (size_t)(L.depth + 1) * (a.act_stride / 32) : nullptr, unused, mrow0, ncol0, row0, total, lane);
         __syncthreads();
     }
+    if (SAVE) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, a.act_save + (size_t)(L.depth + 1) * a.act_stride, row0, total, tid);
     // ---- SH output layer (27 -> 32 padded outputs): one 32-row m-tile per wave
     for (int mt = wave; mt < MT / 32; mt += WAVES) {
         f32x16 a1[1][1];
@@ -244,13 +264,13 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
 template <int WIDTH>
 static hipError_t launch_fwd_h(const McnMlpFwdArgs& a, long long max_rows, hipStream_t st) {
     using SM = FwdSmemH<WIDTH>;
-    const int grid = (int)((max_rows + SM::MT - 1) / SM::MT);
+    const int grid = (int)((max_rows + MCN_GROUPS * SM::MT - 1) / (MCN_GROUPS * SM::MT));      // MCN_GROUPS tiles per workgroup
     if (grid <= 0) return hipSuccess;
     const bool save = a.act_save != nullptr;
     auto kern = save ? mlp_fwd_h_kernel<WIDTH, true> : mlp_fwd_h_kernel<WIDTH, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MCN_GROUPS * SM::bytes));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(SM::NT), SM::bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MCN_GROUPS * SM::NT), MCN_GROUPS * SM::bytes, st, a);
     return hipGetLastError();
 }
 

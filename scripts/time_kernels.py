@@ -1,0 +1,45 @@
+"""Times the fine-net forward / backward chain / weight-gradient calls alone at bench scale (dense rays x 128).
+    python scripts/time_kernels.py [precision] [rays] [width]      (MCNERF_LIB=... selects an ablation build)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import mcnerf_oracle as O
+from mc_nerf_amd import ops
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 25600
+width = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+S = 128
+dev = torch.device("cuda:0")
+nc = {256: O.NetCfg(8, 256, (4,)), 128: O.NetCfg(4, 128, (2,))}[width]
+net = ops.Net(nc.depth, nc.width, nc.skips[0])
+p = O.init_params(nc, 7)
+flat = ops.flatten_params(net, [p[k].to(dev) for k in net.names()], dev)
+g = torch.Generator(device=dev).manual_seed(0)
+o = torch.nn.functional.normalize(torch.randn(N, 3, device=dev, generator=g), dim=-1) * 3
+d = torch.nn.functional.normalize(-o + 0.5 * torch.randn(N, 3, device=dev, generator=g), dim=-1)
+zg = torch.linspace(1, 8, S, device=dev)
+bw = torch.ones(10, device=dev)
+packed = ops.pack_weights(net, flat, precision=prec)
+out = torch.empty(N, S, 4, device=dev)
+save = ops.alloc_save(net, N * S, dev)
+d_out = torch.randn(N, S, 4, device=dev, generator=g) * 1e-4
+gmax = d_out.abs().max().reshape(1).view(torch.int32)
+dy, dsh = torch.empty_like(save.act), torch.empty_like(save.sh)
+grads = torch.zeros_like(flat)
+d_o, d_d = torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev)
+fns = {
+    "fwd": lambda: ops.mlp_fwd(net, flat, packed, o, d, zg, None, bw, out, save=save, precision=prec),
+    "fwd_nosave": lambda: ops.mlp_fwd(net, flat, packed, o, d, zg, None, bw, out, precision=prec),
+    "bwd": lambda: ops.mlp_bwd(net, flat, packed, o, d, zg, None, bw, out, d_out, save, dy, dsh, d_o, d_d, precision=prec, gmax=gmax),
+    "dw": lambda: ops.mlp_dw(net, save, dy, dsh, grads, N * S, precision=prec, gmax=gmax),
+}
+res = []
+for name, fn in fns.items():
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 4
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    res.append(f"{name} {e0.elapsed_time(e1) / reps:7.2f} ms")
+print(os.environ.get("MCNERF_LIB", "default"), prec, f"rows={N * S}", " | ".join(res), "finite", bool(torch.isfinite(out).all()))
