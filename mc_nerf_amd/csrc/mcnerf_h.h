@@ -18,6 +18,20 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #ifndef MCN_GROUPS          // tiles (wave groups) per workgroup of the split-f16 forward / backward chains: 1 | 2 (ping-pong)
 #define MCN_GROUPS 1
 #endif
+// Tile geometry of the split-f16 forward / backward chains (defaults = McnGeom).  MCN_H_WM256 = 2 gives the 256-wide
+// net 128-row tiles on 8 waves, one workgroup per CU: the two waves that share an output slice fetch the same packed
+// weight fragments, so the L2 -> CU weight stream per sample halves.
+#ifndef MCN_H_WM256
+#define MCN_H_WM256 1
+#endif
+template <int WIDTH> struct McnGeomH : McnGeom<WIDTH> { static constexpr int WGS = 2; };
+template <> struct McnGeomH<256> { static constexpr int WN = 4, NI = 2, WM = MCN_H_WM256, MI = 2, WGS = 2 / MCN_H_WM256; };
+#ifndef MCN_GEMM_UNROLL     // k-loop unrolling of mcn_gemm_seg_h: 0 = compiler's choice (full), 1 = rolled, n = by n
+#define MCN_GEMM_UNROLL 0
+#endif
+#ifndef MCN_LDS_FACTOR      // (ablation: 2 = twice the LDS request, i.e. one workgroup per CU)
+#define MCN_LDS_FACTOR 1
+#endif
 #ifndef MCN_COPY_MODE
 #define MCN_COPY_MODE 2
 #endif
@@ -72,6 +86,11 @@ __device__ __forceinline__ void mcn_gemm_seg_h(f32x16 (&acc)[NI][MI], const _Flo
     __builtin_amdgcn_sched_barrier(0);
     pre();
     __builtin_amdgcn_sched_barrier(0);
+#if MCN_GEMM_UNROLL == 1
+#pragma clang loop unroll(disable)      // (KS16 is a constant at every call site: hipcc otherwise unrolls all k-steps,
+#elif MCN_GEMM_UNROLL > 1               //  hoists the weight loads far ahead and spills inside the MFMA stream)
+#pragma clang loop unroll_count(MCN_GEMM_UNROLL)
+#endif
     for (int ks = 0; ks < KS16; ++ks) {
         h8 ach[NI], acl[NI], bh[MI], bl[MI];
 #pragma unroll

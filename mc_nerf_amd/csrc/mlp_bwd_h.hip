@@ -9,7 +9,7 @@
 
 template <int WIDTH>
 struct BwdSmemH {
-    using G = McnGeom<WIDTH>;
+    using G = McnGeomH<WIDTH>;
     static constexpr int MT = G::WM * G::MI * 32;
     static constexpr int NT = G::WN * G::WM * 64;
     static constexpr int XW = WIDTH > 64 ? WIDTH : 64;
@@ -69,8 +69,8 @@ __device__ __forceinline__ void mask_store_h(f32x16 (&acc)[NI][MI], const unsign
 // regions, workgroup-wide barriers, group 1 one barrier behind, so that one group's MFMA phase overlaps the
 // other's mask / split / write-back phase on every SIMD.
 template <int WIDTH>
-__global__ __launch_bounds__(MCN_GROUPS * McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2 / MCN_GROUPS) void mlp_bwd_h_kernel(McnMlpBwdArgs a) {
-    using G = McnGeom<WIDTH>;
+__global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>::WM * 64, McnGeomH<WIDTH>::WGS / MCN_GROUPS) void mlp_bwd_h_kernel(McnMlpBwdArgs a) {
+    using G = McnGeomH<WIDTH>;
     using SM = BwdSmemH<WIDTH>;
     constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN, NT = SM::NT, WAVES = NT / 64;
     constexpr int NSH = WIDTH / 16;           // reduction steps (of 16) over a hidden-wide dY
@@ -296,9 +296,9 @@ static hipError_t launch_bwd_h(const McnMlpBwdArgs& a, long long max_rows, hipSt
     const int grid = (int)((max_rows + MCN_GROUPS * SM::MT - 1) / (MCN_GROUPS * SM::MT));      // MCN_GROUPS tiles per workgroup
     if (grid <= 0) return hipSuccess;
     auto kern = mlp_bwd_h_kernel<WIDTH>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MCN_GROUPS * SM::bytes));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MCN_LDS_FACTOR * MCN_GROUPS * SM::bytes));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MCN_GROUPS * SM::NT), MCN_GROUPS * SM::bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MCN_GROUPS * SM::NT), MCN_LDS_FACTOR * MCN_GROUPS * SM::bytes, st, a);
     return hipGetLastError();
 }
 

@@ -6,9 +6,20 @@
 #include "mcnerf_h.h"
 #include "mcnerf_kernels.h"
 
+#ifdef MCN_STAMPS      // (diagnostic build: in-kernel cycle stamps of one trunk layer, read back by scripts/stamps.py)
+__device__ unsigned long long g_mcn_stamps[64 * 4 * 8];
+extern "C" int mcnerf_debug_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mcn_stamps), sizeof(g_mcn_stamps));
+}
+#define MCN_STAMP(i) do { if (WIDTH == 256 && l == 3 && blockIdx.x >= 2048 && blockIdx.x < 2048 + 64 && lane == 0) \
+        g_mcn_stamps[((blockIdx.x - 2048) * 4 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MCN_STAMP(i) do { } while (0)
+#endif
+
 template <int WIDTH>
 struct FwdSmemH {
-    using G = McnGeom<WIDTH>;
+    using G = McnGeomH<WIDTH>;
     static constexpr int MT = G::WM * G::MI * 32;
     static constexpr int NT = G::WN * G::WM * 64;       // threads per workgroup
     static constexpr int XW = WIDTH > 64 ? WIDTH : 64;
@@ -103,8 +114,8 @@ __device__ __forceinline__ void layer_epilogue_h(f32x16 (&acc)[NI][MI], const fl
 // split / LDS write-back, instead of both drifting into lockstep (measured: MFMA and VALU co-executed in only 6 %
 // of the MFMA-busy cycles with two independent workgroups per CU).
 template <int WIDTH, bool SAVE>
-__global__ __launch_bounds__(MCN_GROUPS * McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2 / MCN_GROUPS) void mlp_fwd_h_kernel(McnMlpFwdArgs a) {
-    using G = McnGeom<WIDTH>;
+__global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>::WM * 64, McnGeomH<WIDTH>::WGS / MCN_GROUPS) void mlp_fwd_h_kernel(McnMlpFwdArgs a) {
+    using G = McnGeomH<WIDTH>;
     using SM = FwdSmemH<WIDTH>;
     constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN, NT = SM::NT, WAVES = NT / 64;
     constexpr int KSH = WIDTH / 16;     // k-steps (of 16) of a hidden segment
@@ -163,6 +174,7 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeom<WIDTH>::WN * McnGeom<WIDTH>::W
     // ---- trunk
     for (int l = 0; l < L.depth; ++l) {
         mcn_zero<NI, MI>(acc);
+        MCN_STAMP(0);
         // a training forward trickles the tile it is reading (encoding / previous layer's output) out to the
         // workspaces during the GEMM, one row group per k-step
         float* const prev = SAVE && l > 0 ? a.act_save + (size_t)(l - 1) * a.act_stride : nullptr;
@@ -182,12 +194,16 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeom<WIDTH>::WN * McnGeom<WIDTH>::W
                 mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSE, pk + (L.fEncS >> 2) + (wn * NI) * KSE * 128, lane);
             }
         }
+        MCN_STAMP(1);
         __syncthreads();
+        MCN_STAMP(2);
         float unused[MI];
         layer_epilogue_h<WIDTH, NI, MI, true, SAVE, false>(acc, prm + L.pB[l], nullptr, Xh, Xl,
             SAVE ? a.act_save + (size_t)l * a.act_stride : nullptr,
             SAVE ? a.mask_save + (size_t)l * (a.act_stride / 32) : nullptr, unused, mrow0, ncol0, row0, total, lane);
+        MCN_STAMP(3);
         __syncthreads();
+        MCN_STAMP(4);
     }
 
     // ---- sigma head: hidden layer on MFMA, the 1-wide output layer lane-local on the VALU
@@ -268,9 +284,9 @@ static hipError_t launch_fwd_h(const McnMlpFwdArgs& a, long long max_rows, hipSt
     if (grid <= 0) return hipSuccess;
     const bool save = a.act_save != nullptr;
     auto kern = save ? mlp_fwd_h_kernel<WIDTH, true> : mlp_fwd_h_kernel<WIDTH, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MCN_GROUPS * SM::bytes));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MCN_LDS_FACTOR * MCN_GROUPS * SM::bytes));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MCN_GROUPS * SM::NT), MCN_GROUPS * SM::bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MCN_GROUPS * SM::NT), MCN_LDS_FACTOR * MCN_GROUPS * SM::bytes, st, a);
     return hipGetLastError();
 }
 

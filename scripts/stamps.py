@@ -1,0 +1,36 @@
+"""Reads the in-kernel cycle stamps of a -DMCN_STAMPS build (trunk layer 3 of 64 steady-state workgroups of the
+split-f16 forward):  MCNERF_LIB=.../libmcnerf_stamps.so python scripts/stamps.py [save|nosave]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import mcnerf_oracle as O
+from mc_nerf_amd import ops, _lib
+mode = sys.argv[1] if len(sys.argv) > 1 else "save"
+dev = torch.device("cuda:0")
+nc = O.NetCfg(8, 256, (4,)); net = ops.Net(8, 256, 4)
+p = O.init_params(nc, 7)
+flat = ops.flatten_params(net, [p[k].to(dev) for k in net.names()], dev)
+N, S = 25600, 128
+g = torch.Generator(device=dev).manual_seed(0)
+o = torch.nn.functional.normalize(torch.randn(N, 3, device=dev, generator=g), dim=-1) * 3
+d = torch.nn.functional.normalize(-o + 0.5 * torch.randn(N, 3, device=dev, generator=g), dim=-1)
+zg = torch.linspace(1, 8, S, device=dev); bw = torch.ones(10, device=dev)
+packed = ops.pack_weights(net, flat, precision="f16x3")
+out = torch.empty(N, S, 4, device=dev)
+save = ops.alloc_save(net, N * S, dev) if mode == "save" else None
+for _ in range(2):
+    ops.mlp_fwd(net, flat, packed, o, d, zg, None, bw, out, save=save, precision="f16x3")
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * (64 * 4 * 8))()
+l = _lib.lib()
+l.mcnerf_debug_stamps.restype = ctypes.c_int
+assert l.mcnerf_debug_stamps(buf) == 0
+t = np.frombuffer(buf, dtype=np.uint64).reshape(64, 4, 8).astype(np.int64)
+names = ["GEMM (incl. copy issue)", "wait at barrier 1", "epilogue", "wait at barrier 2"]
+dt = np.diff(t[:, :, :5], axis=2)
+ok = (t[:, :, 0] > 0)
+print(mode, "workgroups with stamps:", int(ok.all(1).sum()))
+for i, n in enumerate(names):
+    v = dt[:, :, i][ok]
+    print(f"  {n:26s} mean {v.mean():8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f} cycles (100 MHz ticks x?)")
+print("  layer total mean", (t[:, :, 4] - t[:, :, 0])[ok].mean())
