@@ -285,3 +285,104 @@ def test_two_ranks_share_one_gpu_data_parallel(gpu_device):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "two_rank_one_gpu.py")], capture_output=True,
                        text=True, timeout=580)
     assert r.returncode == 0 and "check: OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Full-size (BASELINE configs[1]: 64 + 128 samples, coarse 4x128 + fine 8x256) property tests: sizes the CPU oracle
+# cannot finish, checked through properties that do not depend on the size.
+# ---------------------------------------------------------------------------------------------------------
+def _full_size_model(dev, precision, seed=3):
+    from mc_nerf_amd.model import NeRF_Model
+    cfg = O.RenderCfg(samples=64, scale=2, coarse=O.NetCfg(4, 128, (2,)), fine=O.NetCfg(8, 256, (4,)))
+    m = NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision=precision)).to(dev)
+    m.nerf_coarse.load_state_dict(O.init_params(cfg.coarse, seed))
+    m.nerf_fine.load_state_dict(O.init_params(cfg.fine, seed + 1))
+    return m, cfg
+
+
+def _full_size_inputs(n, cfg, dev, seed=11):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    o = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g), dim=-1) * 4.0
+    d = torch.nn.functional.normalize(-o + 0.7 * torch.randn(n, 3, device=dev, generator=g), dim=-1)
+    S, Sf = cfg.samples, cfg.samples * cfg.scale
+    kw = dict(jitter=torch.rand(n, 1, device=dev, generator=g) * (cfg.far - cfg.near) / S,
+              eps_c=torch.randn(n, S, device=dev, generator=g), eps_sel=torch.randn(n, S, device=dev, generator=g),
+              eps_f=torch.randn(n, Sf, device=dev, generator=g))
+    return d, o, kw
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_full_size_permutation_and_repeatability(gpu_device, precision):
+    """32768 rays at the bench configuration: rendering is a per-ray function (a permutation of the rays permutes the
+    outputs bit-exactly, including through the device-side selection / compaction) and repeatable."""
+    dev = gpu_device
+    m, cfg = _full_size_model(dev, precision)
+    n = 32768
+    d, o, kw = _full_size_inputs(n, cfg, dev)
+    with torch.no_grad():
+        c1, f1 = m.render_rays_train(d, o, 0, 0.5, **kw)
+        k1 = int(m.last_selection[1].item())
+        c2, f2 = m.render_rays_train(d, o, 0, 0.5, **kw)
+        perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+        c3, f3 = m.render_rays_train(d[perm].contiguous(), o[perm].contiguous(), 0, 0.5,
+                                     **{k: v[perm].contiguous() for k, v in kw.items()})
+        k3 = int(m.last_selection[1].item())
+    assert 0 < k1 <= n * cfg.samples * cfg.scale and k1 == k3
+    assert torch.isfinite(f1).all() and torch.isfinite(c1).all()
+    assert torch.equal(c1, c2) and torch.equal(f1, f2)
+    assert torch.equal(c1[perm], c3) and torch.equal(f1[perm], f3)
+
+
+def test_full_size_directional_derivative(gpu_device):
+    """8192 rays at the bench configuration, exact-fp32 mode: <grad, v> from the hand-written backward against a
+    central finite difference of the loss along a random direction v in the fine net's parameters (the coarse pass,
+    hence the fine-sample selection, is unaffected, so the loss is smooth along v)."""
+    dev = gpu_device
+    m, cfg = _full_size_model(dev, "f32")
+    n = 8192
+    d, o, kw = _full_size_inputs(n, cfg, dev, seed=17)
+    gt = torch.rand(n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    from mc_nerf_amd.model import MC_NeRF_Loss
+    L = MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800))
+    def loss_at():
+        c, f = m.render_rays_train(d, o, 0, 0.5, **kw)
+        return L.get_rgb_loss([c, f, gt])
+
+    loss = loss_at()
+    sel0 = m.last_selection[0][: int(m.last_selection[1].item())].clone()
+    loss.backward()
+    params = [p for p in m.nerf_fine.parameters()]
+    gen = torch.Generator(device=dev).manual_seed(9)
+    vs = [torch.randn(p.shape, device=dev, generator=gen) * p.detach().abs().mean() for p in params]
+    analytic = sum(float((p.grad.double() * v.double()).sum()) for p, v in zip(params, vs))
+    h = 2e-3
+    vals = []
+    with torch.no_grad():
+        for sgn in (+1, -1):
+            for p, v in zip(params, vs):
+                p.add_(sgn * h * v)
+            vals.append(float(loss_at()))
+            assert torch.equal(m.last_selection[0][: int(m.last_selection[1].item())], sel0)
+            for p, v in zip(params, vs):
+                p.sub_(sgn * h * v)
+    fd = (vals[0] - vals[1]) / (2 * h)
+    assert abs(fd - analytic) <= 2e-2 * max(abs(analytic), 1e-4), (fd, analytic)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("n", [1, 63, 257])
+def test_ragged_small_batches_match_oracle(gpu_device, n, precision):
+    """Ray counts around the tile sizes (1 ray, 63, 257) on small nets, end to end against the CPU oracle."""
+    dev = gpu_device
+    cfg = O.RenderCfg(samples=32, scale=2, coarse=O.NetCfg(4, 32, (2,)), fine=O.NetCfg(8, 64, (4,)))
+    from mc_nerf_amd.model import NeRF_Model
+    m = NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision=precision)).to(dev)
+    pc, pf = O.init_params(cfg.coarse, 21), O.init_params(cfg.fine, 22)
+    m.nerf_coarse.load_state_dict(pc)
+    m.nerf_fine.load_state_dict(pf)
+    d, o, kw = _full_size_inputs(n, cfg, torch.device("cpu"), seed=n)
+    r = O.render_rays_train(pc, pf, cfg, d, o, 0.5, kw["jitter"], kw["eps_c"], kw["eps_sel"], kw["eps_f"])
+    c, f = m.render_rays_train(d.to(dev), o.to(dev), 0, 0.5, **{k: v.to(dev) for k, v in kw.items()})
+    assert err(c, r["rgb_c"].detach().numpy()) < TOL and err(f, r["rgb_f"].detach().numpy()) < TOL
+    k = int(m.last_selection[1].item())
+    assert k == r["idx_f"].shape[0] and torch.equal(m.last_selection[0][:k].cpu().long(), r["idx_f"])
