@@ -15,8 +15,20 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-#ifndef MCN_GROUPS          // tiles (wave groups) per workgroup of the split-f16 forward / backward chains: 1 | 2 (ping-pong)
-#define MCN_GROUPS 1
+// Store waves (training forward / backward chains of the wider nets): the workgroup gets 4 extra waves that never
+// load weights and do nothing but copy the finished LDS tiles (and the ReLU bit masks) to the HBM workspaces.  On
+// gfx950 loads and stores retire through ONE in-order vmcnt, so a wave that stores a tile cannot consume a later
+// weight load before the stores are acknowledged; with the stores on other waves the MFMA waves never wait for the
+// ~35 GB workspace drain.  One such workgroup per CU (MCN_HELP_MIN_WIDTH = narrowest net that uses them; 0 = off).
+#ifndef MCN_HELP_MIN_WIDTH
+#define MCN_HELP_MIN_WIDTH 0
+#endif
+#ifndef MCN_HELP_THREADS
+#define MCN_HELP_THREADS 256        // 256: one workgroup (4 MFMA + 4 store waves) per CU at 256 registers; 128: two per CU at 168
+#endif
+#define MCN_HELP_WGS (MCN_HELP_THREADS <= 128 ? 2 : 1)
+#ifndef MCN_HELP_PRIO
+#define MCN_HELP_PRIO 3
 #endif
 // Tile geometry of the split-f16 forward / backward chains (defaults = McnGeom).  MCN_H_WM256 = 2 gives the 256-wide
 // net 128-row tiles on 8 waves, one workgroup per CU: the two waves that share an output slice fetch the same packed
@@ -28,9 +40,6 @@ template <int WIDTH> struct McnGeomH : McnGeom<WIDTH> { static constexpr int WGS
 template <> struct McnGeomH<256> { static constexpr int WN = 4, NI = 2, WM = MCN_H_WM256, MI = 2, WGS = 2 / MCN_H_WM256; };
 #ifndef MCN_GEMM_UNROLL     // k-loop unrolling of mcn_gemm_seg_h: 0 = compiler's choice (full), 1 = rolled, n = by n
 #define MCN_GEMM_UNROLL 0
-#endif
-#ifndef MCN_LDS_FACTOR      // (ablation: 2 = twice the LDS request, i.e. one workgroup per CU)
-#define MCN_LDS_FACTOR 1
 #endif
 #ifndef MCN_COPY_MODE
 #define MCN_COPY_MODE 2
@@ -196,16 +205,67 @@ __device__ __forceinline__ void mcn_copy_tile_trip(const _Float16* Xh, const _Fl
     if (row0 + m < total) *reinterpret_cast<u32x4*>(dst + (size_t)(row0 + m) * COLS + n4) = w;
 #endif
 }
-template <int MT, int XW, int COLS, int NT>
+template <int MT, int XW, int COLS, int NT, int U = 4>
 __device__ __forceinline__ void mcn_copy_tile_words(const _Float16* Xh, const _Float16* Xl, float* __restrict__ dst,
                                                     long long row0, long long total, int tid) {
-    constexpr int TRIPS = MT * (COLS / 4) / NT, U = TRIPS < 4 ? TRIPS : 4;      // groups of U keep the register footprint small
-    static_assert((MT * (COLS / 4)) % NT == 0 && TRIPS % U == 0, "tile copy shape");
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    constexpr int C4 = COLS / 4, TRIPS = MT * C4 / NT, UU = TRIPS < U ? TRIPS : U;
+    static_assert((MT * C4) % NT == 0 && TRIPS % UU == 0, "tile copy shape");
+    if (row0 + MT <= total) {
+        // whole tile inside the batch (all but the last workgroup): unpredicated, UU trips in flight -- the LDS reads of
+        // a group are issued back to back and their latency is paid once per group, not once per row
 #pragma unroll 1
-    for (int k0 = 0; k0 < TRIPS; k0 += U)
+        for (int k0 = 0; k0 < TRIPS; k0 += UU) {
+            u2 H[UU], L[UU];
 #pragma unroll
-        for (int k = k0; k < k0 + U; ++k) mcn_copy_tile_trip<MT, XW, COLS, NT>(Xh, Xl, dst, row0, total, tid, k);
+            for (int k = 0; k < UU; ++k) {
+                const int it = tid + (k0 + k) * NT;
+                const int m = it / C4, n4 = 4 * (it - m * C4);
+                const int o = mcn_hoff<XW>(m, n4 >> 3) + (n4 & 7);
+                H[k] = *reinterpret_cast<const u2*>(Xh + o);
+                L[k] = *reinterpret_cast<const u2*>(Xl + o);
+            }
+#pragma unroll
+            for (int k = 0; k < UU; ++k) {
+                const int it = tid + (k0 + k) * NT;
+                const int m = it / C4, n4 = 4 * (it - m * C4);
+                u32x4 w;
+                w[0] = __builtin_amdgcn_perm(L[k][0], H[k][0], 0x05040100u);
+                w[1] = __builtin_amdgcn_perm(L[k][0], H[k][0], 0x07060302u);
+                w[2] = __builtin_amdgcn_perm(L[k][1], H[k][1], 0x05040100u);
+                w[3] = __builtin_amdgcn_perm(L[k][1], H[k][1], 0x07060302u);
+#if defined(ABL_NOSTORE)
+                if (total < 0)
+#endif
+                *reinterpret_cast<u32x4*>(dst + (size_t)(row0 + m) * COLS + n4) = w;
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < TRIPS; ++k) mcn_copy_tile_trip<MT, XW, COLS, NT>(Xh, Xl, dst, row0, total, tid, k);
+    }
 }
+// ReLU bit masks of the split LDS tile (bit = activation > 0 = its hi half is non-zero), 32 columns per word, row-major
+// [rows][WIDTH / 32] as the forward's epilogue used to write them: a thread takes 4 columns (one nibble), 8 neighbouring
+// lanes assemble a word with three exchanges.
+template <int MT, int XW, int WIDTH, int NT>
+__device__ __forceinline__ void mcn_tile_masks(const _Float16* Xh, unsigned* __restrict__ msave, long long row0, long long total, int tid) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    constexpr int C4 = WIDTH / 4, TRIPS = MT * C4 / NT;
+    static_assert((MT * C4) % NT == 0 && C4 % 8 == 0 && NT % 8 == 0, "mask tile shape");
+#pragma unroll 4
+    for (int k = 0; k < TRIPS; ++k) {
+        const int it = tid + k * NT;
+        const int m = it / C4, c4 = it - m * C4, n4 = 4 * c4;
+        const u2 H = *reinterpret_cast<const u2*>(Xh + mcn_hoff<XW>(m, n4 >> 3) + (n4 & 7));
+        unsigned x = ((H[0] & 0xffffu) ? 1u : 0u) | ((H[0] >> 16) ? 2u : 0u) | ((H[1] & 0xffffu) ? 4u : 0u) | ((H[1] >> 16) ? 8u : 0u);
+        x |= (unsigned)__shfl_xor((int)x, 1) << 4;        // valid on even lanes
+        x |= (unsigned)__shfl_xor((int)x, 2) << 8;        // valid on lanes = 0 mod 4
+        x |= (unsigned)__shfl_xor((int)x, 4) << 16;       // valid on lanes = 0 mod 8
+        if ((c4 & 7) == 0 && row0 + m < total) msave[(size_t)(row0 + m) * (WIDTH / 32) + (c4 >> 3)] = x;
+    }
+}
+
 template <int MT, int XW, int COLS, int NT, int KS>
 __device__ __forceinline__ void mcn_copy_tile_step(const _Float16* Xh, const _Float16* Xl, float* __restrict__ dst,
                                                    long long row0, long long total, int tid, int ks) {

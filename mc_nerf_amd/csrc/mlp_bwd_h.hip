@@ -65,19 +65,17 @@ __device__ __forceinline__ void mask_store_h(f32x16 (&acc)[NI][MI], const unsign
         }
 }
 
-// Two tiles per workgroup in ping-pong (see mlp_fwd_h.hip): group 0 = waves 0-3, group 1 = waves 4-7, own LDS
-// regions, workgroup-wide barriers, group 1 one barrier behind, so that one group's MFMA phase overlaps the
-// other's mask / split / write-back phase on every SIMD.
-template <int WIDTH>
-__global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>::WM * 64, McnGeomH<WIDTH>::WGS / MCN_GROUPS) void mlp_bwd_h_kernel(McnMlpBwdArgs a) {
+// HELP: store waves (mcnerf_h.h) mirror the barrier sequence below and copy every dY tile to dy_save while the MFMA
+// waves run the GEMM that reads it; without them the MFMA waves issue those copies themselves.
+template <int WIDTH, bool HELP>
+__device__ __forceinline__ void mlp_bwd_h_body(const McnMlpBwdArgs& a) {
     using G = McnGeomH<WIDTH>;
     using SM = BwdSmemH<WIDTH>;
     constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN, NT = SM::NT, WAVES = NT / 64;
     constexpr int NSH = WIDTH / 16;           // reduction steps (of 16) over a hidden-wide dY
     constexpr int W4 = WIDTH / 4;
-    extern __shared__ __attribute__((aligned(16))) float smem_all[];
-    const int grp = MCN_GROUPS > 1 ? threadIdx.x / NT : 0;                     // 0 | 1 (wave-uniform)
-    float* smem = smem_all + grp * SM::total;
+    constexpr bool COPY = !HELP;              // the MFMA waves save the dY tiles themselves
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Xh = reinterpret_cast<_Float16*>(smem + SM::oX);
     _Float16* Xl = Xh + MT * XW;
     float* Xf = smem + SM::oX;                // fp32 view of the same region for the final encoding-gradient stage
@@ -87,18 +85,43 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>:
     int* sray = reinterpret_cast<int*>(smem + SM::oAddr);
     float* sz = smem + SM::oZ;
 
-    const int tid = threadIdx.x - grp * NT, lane = tid & 63, wave = tid >> 6;      // group-local ids
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN;
     const int mrow0 = wm * MI * 32, ncol0 = wn * NI * 32;
     const long long total = a.count ? (long long)min(*a.count, a.max_rows) : (long long)a.n_rays * a.S;
-    const long long row0 = ((long long)blockIdx.x * MCN_GROUPS + grp) * MT;
-    if (row0 >= total) return;            // (a finished wave no longer counts at the workgroup's barriers)
+    const long long row0 = (long long)blockIdx.x * MT;
+    if (row0 >= total) return;
     const McnLayout& L = a.lay;
     const int D = L.depth;
     const float* __restrict__ prm = a.params;
     const h8* __restrict__ pk = reinterpret_cast<const h8*>(a.packed);     // split-f16 transposed packed weights
     const size_t AS = a.act_stride;
-    if (MCN_GROUPS > 1 && grp == 1) __syncthreads();        // phase offset: group 1 runs one barrier behind group 0
+
+    if (HELP && __builtin_amdgcn_readfirstlane(tid) >= NT) {
+        // ---- store waves: one __syncthreads() for every one of the MFMA waves below, in the same order
+        constexpr int HT = MCN_HELP_THREADS;
+        const int ht = tid - NT;
+        __builtin_amdgcn_s_setprio(MCN_HELP_PRIO);        // the store waves are light: let them issue ahead of the MFMA wave on their SIMD
+        __syncthreads();                                   // prologue done (X = dsh)
+        __syncthreads();                                   // sh.2^T GEMM done
+        __syncthreads();                                   // X = dY of sh.0
+        mcn_copy_tile_words<MT, XW, WIDTH, HT, 8>(Xh, Xl, a.dy_save + (size_t)(D + 1) * AS, row0, total, ht);
+        __syncthreads();                                   // sh.0^T GEMM done
+        __syncthreads();                                   // X = dY of sigma.0
+        mcn_copy_tile_words<MT, XW, WIDTH, HT, 8>(Xh, Xl, a.dy_save + (size_t)D * AS, row0, total, ht);
+        __syncthreads();                                   // sigma.0^T GEMM done
+        __syncthreads();                                   // X = dY_{D-1}
+        for (int l = D - 1; l >= 0; --l) {
+            mcn_copy_tile_words<MT, XW, WIDTH, HT, 8>(Xh, Xl, a.dy_save + (size_t)l * AS, row0, total, ht);   // X = dY_l
+            if (l == 0) break;
+            __syncthreads();                               // GEMM of layer l done
+            __syncthreads();                               // X = dY_{l-1}
+        }
+        __syncthreads();                                   // encoded-gradient GEMMs done
+        __syncthreads();                                   // encoded-input gradient in LDS
+        if (a.d_rays_o || a.d_rays_d) __syncthreads();     // per-sample d o / d d in LDS
+        return;
+    }
     // gradient scale: a power of two that puts max|d_out| of this launch near 2^4 in f16 (4096x headroom below
     // the f16 maximum for growth through the layers, ~2^-18 of the maximum before f16 subnormals start)
     const float gmax = a.gmax_bits ? __uint_as_float(*a.gmax_bits) : 1.f;
@@ -169,8 +192,8 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>:
     {
         float* const dst = a.dy_save + (size_t)(D + 1) * AS;
         mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, NSH, pk + (L.bC1 >> 2) + (wn * NI) * NSH * 128, lane,
-            [=](int ks) { mcn_copy_tile_step<MT, XW, WIDTH, NT, NSH>(Xh, Xl, dst, row0, total, tid, ks); },
-            [=]() { if (MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, dst, row0, total, tid); });
+            [=](int ks) { if (COPY) mcn_copy_tile_step<MT, XW, WIDTH, NT, NSH>(Xh, Xl, dst, row0, total, tid, ks); },
+            [=]() { if (COPY && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, dst, row0, total, tid); });
     }
     __syncthreads();
     {   // dY of sigma.0 = d sigma * w_sigma2 masked by hs > 0 (outer product, no GEMM)
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>:
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ((w >> e) & 1u) ? ds * ww[e] : 0.f;
             const u32x4 w4 = store_split4_s<XW>(Xh, Xl, m, 4 * c4, v, sg);
-            if (ok) *reinterpret_cast<u32x4*>(dys + (size_t)(row0 + m) * WIDTH + 4 * c4) = w4;
+            if (COPY && ok) *reinterpret_cast<u32x4*>(dys + (size_t)(row0 + m) * WIDTH + 4 * c4) = w4;
         }
     }
     __syncthreads();
@@ -219,13 +242,13 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>:
         }
         float* const dst = a.dy_save + (size_t)l * AS;           // X holds dY_l
         if (l == 0) {
-            mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, dst, row0, total, tid);
+            if (COPY) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, dst, row0, total, tid);
             break;
         }
         mcn_zero<NI, MI>(acc);
         mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, NSH, pk + (L.bH[l] >> 2) + (wn * NI) * NSH * 128, lane,
-            [=](int ks) { mcn_copy_tile_step<MT, XW, WIDTH, NT, NSH>(Xh, Xl, dst, row0, total, tid, ks); },
-            [=]() { if (MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, dst, row0, total, tid); });
+            [=](int ks) { if (COPY) mcn_copy_tile_step<MT, XW, WIDTH, NT, NSH>(Xh, Xl, dst, row0, total, tid, ks); },
+            [=]() { if (COPY && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, dst, row0, total, tid); });
         __syncthreads();
         mask_store_h<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(l - 1) * (AS / 32), Xh, Xl, inv, sg, mrow0, ncol0, row0, total, lane);
         __syncthreads();
@@ -291,14 +314,27 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>:
 }
 
 template <int WIDTH>
+__global__ __launch_bounds__(McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>::WM * 64, McnGeomH<WIDTH>::WGS)
+void mlp_bwd_h_kernel(McnMlpBwdArgs a) { mlp_bwd_h_body<WIDTH, false>(a); }
+
+#if MCN_HELP_WGS == 2
+#define MCN_HELP_KERNEL_ATTR __attribute__((amdgpu_flat_work_group_size(64, 384), amdgpu_waves_per_eu(3, 3)))
+#else
+#define MCN_HELP_KERNEL_ATTR __launch_bounds__(256 + MCN_HELP_THREADS, 1)
+#endif
+template <int WIDTH>
+__global__ MCN_HELP_KERNEL_ATTR void mlp_bwd_h_help_kernel(McnMlpBwdArgs a) { mlp_bwd_h_body<WIDTH, true>(a); }
+
+template <int WIDTH>
 static hipError_t launch_bwd_h(const McnMlpBwdArgs& a, long long max_rows, hipStream_t st) {
     using SM = BwdSmemH<WIDTH>;
-    const int grid = (int)((max_rows + MCN_GROUPS * SM::MT - 1) / (MCN_GROUPS * SM::MT));      // MCN_GROUPS tiles per workgroup
+    const int grid = (int)((max_rows + SM::MT - 1) / SM::MT);
     if (grid <= 0) return hipSuccess;
-    auto kern = mlp_bwd_h_kernel<WIDTH>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MCN_LDS_FACTOR * MCN_GROUPS * SM::bytes));
+    constexpr bool HELP = MCN_HELP_MIN_WIDTH > 0 && WIDTH >= MCN_HELP_MIN_WIDTH;
+    auto kern = HELP ? mlp_bwd_h_help_kernel<WIDTH> : mlp_bwd_h_kernel<WIDTH>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM::bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MCN_GROUPS * SM::NT), MCN_LDS_FACTOR * MCN_GROUPS * SM::bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SM::NT + (HELP ? MCN_HELP_THREADS : 0)), SM::bytes, st, a);
     return hipGetLastError();
 }
 

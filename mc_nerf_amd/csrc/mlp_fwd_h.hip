@@ -7,14 +7,17 @@
 #include "mcnerf_kernels.h"
 
 #ifdef MCN_STAMPS      // (diagnostic build: in-kernel cycle stamps of one trunk layer, read back by scripts/stamps.py)
-__device__ unsigned long long g_mcn_stamps[64 * 4 * 8];
+__device__ unsigned long long g_mcn_stamps[64 * 8 * 8];
 extern "C" int mcnerf_debug_stamps(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mcn_stamps), sizeof(g_mcn_stamps));
 }
+#define MCN_STAMP_T(i) do { if (WIDTH == 256 && blockIdx.x >= 2048 && blockIdx.x < 2048 + 64 && lane == 0) \
+        g_mcn_stamps[((blockIdx.x - 2048) * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #define MCN_STAMP(i) do { if (WIDTH == 256 && l == 3 && blockIdx.x >= 2048 && blockIdx.x < 2048 + 64 && lane == 0) \
-        g_mcn_stamps[((blockIdx.x - 2048) * 4 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+        g_mcn_stamps[((blockIdx.x - 2048) * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MCN_STAMP(i) do { } while (0)
+#define MCN_STAMP_T(i) do { } while (0)
 #endif
 
 template <int WIDTH>
@@ -29,7 +32,8 @@ struct FwdSmemH {
     static constexpr int oSig = oDir + MT * 4;         // [WN][MT] partial sigma
     static constexpr int oSh = oSig + G::WN * MT;      // [MT][33] sh coefficients
     static constexpr int oAddr = oSh + MT * 33;        // [MT] int: ray*S + j  (or -1)
-    static constexpr int total = oAddr + MT;
+    static constexpr int oMask = oAddr + MT;           // [MT][WIDTH / 32] ReLU bit masks of the layer just finished (store-wave builds)
+    static constexpr int total = oMask + MT * (WIDTH / 32);
     static constexpr size_t bytes = (size_t)total * 4;
 };
 
@@ -65,7 +69,7 @@ __device__ __forceinline__ void write_encoding_h(_Float16* Xh, _Float16* Xl, con
 //   DOT    : accumulate sum_n v[n] * w2[n] per sample (the 1-wide sigma output layer, lane-local)
 // A lane holds 16 of the 32 columns of its row per tile (the other 16 sit in lane ^ 32), so the mask halves
 // are combined with one cross-lane move.
-template <int WIDTH, int NI, int MI, bool TO_LDS, bool SAVE, bool DOT>
+template <int WIDTH, int NI, int MI, bool TO_LDS, bool SAVE, bool DOT, bool MASKS = SAVE, bool LMASK = false>
 __device__ __forceinline__ void layer_epilogue_h(f32x16 (&acc)[NI][MI], const float* __restrict__ bias, const float* __restrict__ w2,
                                                _Float16* Xh, _Float16* Xl, float* __restrict__ save, unsigned int* __restrict__ msave,
                                                float (&dot)[MI], int mrow0, int ncol0, long long row0, long long total, int lane) {
@@ -87,7 +91,7 @@ __device__ __forceinline__ void layer_epilogue_h(f32x16 (&acc)[NI][MI], const fl
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = fmaxf(acc[ni][mi][4 * q + e] * (1.0f / (MCN_SW * MCN_SX)) + bb[e], 0.f);
-                    if (SAVE) bits |= (v[e] > 0.f ? 1u : 0u) << (8 * q + 4 * h + e);
+                    if (MASKS) bits |= (v[e] > 0.f ? 1u : 0u) << (8 * q + 4 * h + e);
                 }
                 if (DOT) {
                     const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + n4);
@@ -100,29 +104,27 @@ __device__ __forceinline__ void layer_epilogue_h(f32x16 (&acc)[NI][MI], const fl
                 // (layers that go to the LDS tile are saved from there, row-coalesced: mcn_copy_tile_words)
                 if (SAVE && !TO_LDS && ok) *reinterpret_cast<u32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = w;     // split words
             }
-            if (SAVE) {
+            if (MASKS) {
                 const unsigned w = bits | (unsigned)__shfl_xor((int)bits, 32);
-                if (h == 0 && ok) msave[(size_t)(row0 + m) * (WIDTH / 32) + (ncol0 >> 5) + ni] = w;
+                if (LMASK) { if (h == 0) msave[m * (WIDTH / 32) + (ncol0 >> 5) + ni] = w; }          // msave = LDS mask tile
+                else if (h == 0 && ok) msave[(size_t)(row0 + m) * (WIDTH / 32) + (ncol0 >> 5) + ni] = w;
             }
         }
 }
 
-// Two tiles per workgroup, "ping-pong": waves 0-3 (group 0) and waves 4-7 (group 1) each run the whole per-tile
-// program on their own LDS region, but every barrier is workgroup-wide and group 1 starts one barrier late.  The
-// program alternates MFMA phases (layer GEMMs) and VALU/LDS phases (epilogues) separated by barriers, so the two
-// waves that share a SIMD are held in opposite phases: one feeds the matrix pipe while the other does bias / ReLU /
-// split / LDS write-back, instead of both drifting into lockstep (measured: MFMA and VALU co-executed in only 6 %
-// of the MFMA-busy cycles with two independent workgroups per CU).
-template <int WIDTH, bool SAVE>
-__global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>::WM * 64, McnGeomH<WIDTH>::WGS / MCN_GROUPS) void mlp_fwd_h_kernel(McnMlpFwdArgs a) {
+// HELP: the workgroup carries MCN_HELP_THREADS extra threads ("store waves", mcnerf_h.h) that mirror the barrier
+// sequence of the MFMA waves and, between barriers, copy the tile that the MFMA waves are reading (the encoding, then
+// each layer's output) and its ReLU masks to the workspaces.
+template <int WIDTH, bool SAVE, bool HELP>
+__device__ __forceinline__ void mlp_fwd_h_body(const McnMlpFwdArgs& a) {
     using G = McnGeomH<WIDTH>;
     using SM = FwdSmemH<WIDTH>;
     constexpr int MT = SM::MT, XW = SM::XW, NI = G::NI, MI = G::MI, WN = G::WN, NT = SM::NT, WAVES = NT / 64;
     constexpr int KSH = WIDTH / 16;     // k-steps (of 16) of a hidden segment
     constexpr int KSE = MCN_ENCP / 16;  // ... of the encoded segment
-    extern __shared__ __attribute__((aligned(16))) float smem_all[];
-    const int grp = MCN_GROUPS > 1 ? threadIdx.x / NT : 0;                     // 0 | 1 (wave-uniform)
-    float* smem = smem_all + grp * SM::total;
+    constexpr bool COPY = SAVE && !HELP;   // the MFMA waves save the tiles themselves
+    static_assert(!HELP || SAVE, "store waves only exist in the saving instantiation");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Xh = reinterpret_cast<_Float16*>(smem + SM::oX);
     _Float16* Xl = Xh + MT * XW;
     float* sxyz = smem + SM::oXyz;
@@ -131,19 +133,61 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>:
     float* ssh = smem + SM::oSh;
     int* saddr = reinterpret_cast<int*>(smem + SM::oAddr);
 
-    const int tid = threadIdx.x - grp * NT, lane = tid & 63, wave = tid >> 6;      // group-local ids
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN;
     const int r = lane & 31, h = lane >> 5;
     const int mrow0 = wm * MI * 32;
     const int ncol0 = wn * NI * 32;
     const long long total = a.count ? (long long)min(*a.count, a.max_rows) : (long long)a.n_rays * a.S;
-    const long long row0 = ((long long)blockIdx.x * MCN_GROUPS + grp) * MT;
-    if (row0 >= total) return;            // (a finished wave no longer counts at the workgroup's barriers)
+    const long long row0 = (long long)blockIdx.x * MT;
+    if (row0 >= total) return;
     const McnLayout& L = a.lay;
     const float* __restrict__ prm = a.params;
     const h8* __restrict__ pk = reinterpret_cast<const h8*>(a.packed);     // split-f16 packed weights (16-byte units)
-    if (MCN_GROUPS > 1 && grp == 1) __syncthreads();        // phase offset: group 1 runs one barrier behind group 0
 
+    if (HELP && __builtin_amdgcn_readfirstlane(tid) >= NT) {
+        // ---- store waves: one __syncthreads() for every one of the MFMA waves below, in the same order
+        constexpr int HT = MCN_HELP_THREADS;
+        const int ht = tid - NT;
+        __builtin_amdgcn_s_setprio(MCN_HELP_PRIO);        // the store waves are light: let them issue ahead of the MFMA wave on their SIMD
+        const size_t AS = a.act_stride;
+        unsigned* const msk = a.mask_save;
+        const unsigned* const smask = reinterpret_cast<const unsigned*>(smem + SM::oMask);
+        // the finished layer's mask tile [MT][WIDTH/32] is one contiguous block of the workspace rows row0 .. row0+MT-1
+        auto copy_masks = [&](int slot) {
+            constexpr int W32 = WIDTH / 32;
+            for (int i = ht; i < MT * W32; i += HT)
+                if (row0 + i / W32 < total) msk[(size_t)slot * (AS / 32) + (size_t)row0 * W32 + i] = smask[i];
+        };
+        __syncthreads();                                   // per-sample setup done
+        __syncthreads();                                   // encoding in X
+        for (int l = 0; l < L.depth; ++l) {
+            if (l == 0) {
+                mcn_copy_tile_words<MT, XW, MCN_ENCP, HT>(Xh, Xl, a.enc_save, row0, total, ht);
+            } else {                                       // X = output of layer l-1, stable until this layer's epilogue
+                MCN_STAMP(0);
+                mcn_copy_tile_words<MT, XW, WIDTH, HT, 8>(Xh, Xl, a.act_save + (size_t)(l - 1) * AS, row0, total, ht);
+                MCN_STAMP(1);
+                copy_masks(l - 1);
+                MCN_STAMP(2);
+            }
+            if (l == L.skip) { __syncthreads(); __syncthreads(); }     // re-encoding of the skip layer
+            __syncthreads();                               // GEMM done
+            MCN_STAMP(3);
+            __syncthreads();                               // epilogue done
+            MCN_STAMP(4);
+        }
+        mcn_copy_tile_words<MT, XW, WIDTH, HT, 8>(Xh, Xl, a.act_save + (size_t)(L.depth - 1) * AS, row0, total, ht);
+        copy_masks(L.depth - 1);
+        __syncthreads();                                   // sigma head + SH hidden GEMM done
+        __syncthreads();                                   // SH hidden layer in X
+        mcn_copy_tile_words<MT, XW, WIDTH, HT, 8>(Xh, Xl, a.act_save + (size_t)(L.depth + 1) * AS, row0, total, ht);
+        copy_masks(L.depth + 1);
+        __syncthreads();                                   // SH output layer done
+        return;
+    }
+
+    MCN_STAMP_T(5);
     // ---- per-sample setup: position, direction, output address
     for (int m = tid; m < MT; m += NT) {
         const long long g = row0 + m;
@@ -177,16 +221,16 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>:
         MCN_STAMP(0);
         // a training forward trickles the tile it is reading (encoding / previous layer's output) out to the
         // workspaces during the GEMM, one row group per k-step
-        float* const prev = SAVE && l > 0 ? a.act_save + (size_t)(l - 1) * a.act_stride : nullptr;
+        float* const prev = COPY && l > 0 ? a.act_save + (size_t)(l - 1) * a.act_stride : nullptr;
         if (l == 0) {
             float* const encs = a.enc_save;
             mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSE, pk + (L.fEnc0 >> 2) + (wn * NI) * KSE * 128, lane,
-                [=](int ks) { if (SAVE) mcn_copy_tile_step<MT, XW, MCN_ENCP, NT, KSE>(Xh, Xl, encs, row0, total, tid, ks); },
-                [=]() { if (SAVE && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, MCN_ENCP, NT>(Xh, Xl, encs, row0, total, tid); });
+                [=](int ks) { if (COPY) mcn_copy_tile_step<MT, XW, MCN_ENCP, NT, KSE>(Xh, Xl, encs, row0, total, tid, ks); },
+                [=]() { if (COPY && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, MCN_ENCP, NT>(Xh, Xl, encs, row0, total, tid); });
         } else {
             mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSH, pk + (L.fH[l] >> 2) + (wn * NI) * KSH * 128, lane,
-                [=](int ks) { if (SAVE) mcn_copy_tile_step<MT, XW, WIDTH, NT, KSH>(Xh, Xl, prev, row0, total, tid, ks); },
-                [=]() { if (SAVE && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, prev, row0, total, tid); });
+                [=](int ks) { if (COPY) mcn_copy_tile_step<MT, XW, WIDTH, NT, KSH>(Xh, Xl, prev, row0, total, tid, ks); },
+                [=]() { if (COPY && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, prev, row0, total, tid); });
             if (l == L.skip) {
                 __syncthreads();                       // everyone finished reading h from X
                 write_encoding_h<MT, XW>(Xh, Xl, sxyz, a.barf_w, tid, NT);
@@ -198,21 +242,23 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>:
         __syncthreads();
         MCN_STAMP(2);
         float unused[MI];
-        layer_epilogue_h<WIDTH, NI, MI, true, SAVE, false>(acc, prm + L.pB[l], nullptr, Xh, Xl,
+        layer_epilogue_h<WIDTH, NI, MI, true, SAVE, false, SAVE, HELP>(acc, prm + L.pB[l], nullptr, Xh, Xl,
             SAVE ? a.act_save + (size_t)l * a.act_stride : nullptr,
-            SAVE ? a.mask_save + (size_t)l * (a.act_stride / 32) : nullptr, unused, mrow0, ncol0, row0, total, lane);
+            HELP ? reinterpret_cast<unsigned*>(smem + SM::oMask) : SAVE ? a.mask_save + (size_t)l * (a.act_stride / 32) : nullptr,
+            unused, mrow0, ncol0, row0, total, lane);
         MCN_STAMP(3);
         __syncthreads();
         MCN_STAMP(4);
     }
 
+    MCN_STAMP_T(6);
     // ---- sigma head: hidden layer on MFMA, the 1-wide output layer lane-local on the VALU
     {
         mcn_zero<NI, MI>(acc);
-        float* const prev = SAVE ? a.act_save + (size_t)(L.depth - 1) * a.act_stride : nullptr;
+        float* const prev = COPY ? a.act_save + (size_t)(L.depth - 1) * a.act_stride : nullptr;
         mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSH, pk + (L.fS1 >> 2) + (wn * NI) * KSH * 128, lane,
-            [=](int ks) { if (SAVE) mcn_copy_tile_step<MT, XW, WIDTH, NT, KSH>(Xh, Xl, prev, row0, total, tid, ks); },
-            [=]() { if (SAVE && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, prev, row0, total, tid); });
+            [=](int ks) { if (COPY) mcn_copy_tile_step<MT, XW, WIDTH, NT, KSH>(Xh, Xl, prev, row0, total, tid, ks); },
+            [=]() { if (COPY && MCN_COPY_MODE == 2) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, prev, row0, total, tid); });
         float s[MI];
         layer_epilogue_h<WIDTH, NI, MI, false, SAVE, true>(acc, prm + L.pBs1, prm + L.pWs2, Xh, Xl,
             SAVE ? a.act_save + (size_t)L.depth * a.act_stride : nullptr,
@@ -229,12 +275,13 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>:
         mcn_gemm_seg_h<XW, NI, MI>(acc, Xh, Xl, mrow0, 0, KSH, pk + (L.fC1 >> 2) + (wn * NI) * KSH * 128, lane);
         __syncthreads();
         float unused[MI];
-        layer_epilogue_h<WIDTH, NI, MI, true, SAVE, false>(acc, prm + L.pBc1, nullptr, Xh, Xl,
+        layer_epilogue_h<WIDTH, NI, MI, true, SAVE, false, SAVE, HELP>(acc, prm + L.pBc1, nullptr, Xh, Xl,
             SAVE ? a.act_save + (size_t)(L.depth + 1) * a.act_stride : nullptr,
-            SAVE ? a.mask_save + (size_t)(L.depth + 1) * (a.act_stride / 32) : nullptr, unused, mrow0, ncol0, row0, total, lane);
+            HELP ? reinterpret_cast<unsigned*>(smem + SM::oMask) : SAVE ? a.mask_save + (size_t)(L.depth + 1) * (a.act_stride / 32) : nullptr,
+            unused, mrow0, ncol0, row0, total, lane);
         __syncthreads();
     }
-    if (SAVE) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, a.act_save + (size_t)(L.depth + 1) * a.act_stride, row0, total, tid);
+    if (COPY) mcn_copy_tile_words<MT, XW, WIDTH, NT>(Xh, Xl, a.act_save + (size_t)(L.depth + 1) * a.act_stride, row0, total, tid);
     // ---- SH output layer (27 -> 32 padded outputs): one 32-row m-tile per wave
     for (int mt = wave; mt < MT / 32; mt += WAVES) {
         f32x16 a1[1][1];
@@ -275,18 +322,34 @@ __global__ __launch_bounds__(MCN_GROUPS * McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>:
             for (int i = 0; i < MCN_NSH; ++i) dst[i] = sh[i];
         }
     }
+    MCN_STAMP_T(7);
 }
+
+template <int WIDTH, bool SAVE>
+__global__ __launch_bounds__(McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>::WM * 64, McnGeomH<WIDTH>::WGS)
+void mlp_fwd_h_kernel(McnMlpFwdArgs a) { mlp_fwd_h_body<WIDTH, SAVE, false>(a); }
+
+// store-wave build of the saving forward: 4 MFMA waves + MCN_HELP_THREADS / 64 store waves per workgroup
+#if MCN_HELP_WGS == 2
+#define MCN_HELP_KERNEL_ATTR __attribute__((amdgpu_flat_work_group_size(64, 384), amdgpu_waves_per_eu(3, 3)))
+#else
+#define MCN_HELP_KERNEL_ATTR __launch_bounds__(256 + MCN_HELP_THREADS, 1)
+#endif
+template <int WIDTH>
+__global__ MCN_HELP_KERNEL_ATTR void mlp_fwd_h_help_kernel(McnMlpFwdArgs a) { mlp_fwd_h_body<WIDTH, true, true>(a); }
 
 template <int WIDTH>
 static hipError_t launch_fwd_h(const McnMlpFwdArgs& a, long long max_rows, hipStream_t st) {
     using SM = FwdSmemH<WIDTH>;
-    const int grid = (int)((max_rows + MCN_GROUPS * SM::MT - 1) / (MCN_GROUPS * SM::MT));      // MCN_GROUPS tiles per workgroup
+    const int grid = (int)((max_rows + SM::MT - 1) / SM::MT);
     if (grid <= 0) return hipSuccess;
     const bool save = a.act_save != nullptr;
-    auto kern = save ? mlp_fwd_h_kernel<WIDTH, true> : mlp_fwd_h_kernel<WIDTH, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MCN_LDS_FACTOR * MCN_GROUPS * SM::bytes));
+    constexpr bool HELP = MCN_HELP_MIN_WIDTH > 0 && WIDTH >= MCN_HELP_MIN_WIDTH;
+    auto kern = !save ? mlp_fwd_h_kernel<WIDTH, false> : HELP ? mlp_fwd_h_help_kernel<WIDTH> : mlp_fwd_h_kernel<WIDTH, true>;
+    const size_t lds = SM::bytes;       // (with store waves the 8 waves x 256 registers fill the CU: one workgroup per CU)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MCN_GROUPS * SM::NT), MCN_LDS_FACTOR * MCN_GROUPS * SM::bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SM::NT + ((save && HELP) ? MCN_HELP_THREADS : 0)), lds, st, a);
     return hipGetLastError();
 }
 

@@ -21,16 +21,23 @@ save = ops.alloc_save(net, N * S, dev) if mode == "save" else None
 for _ in range(2):
     ops.mlp_fwd(net, flat, packed, o, d, zg, None, bw, out, save=save, precision="f16x3")
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * (64 * 4 * 8))()
+buf = (ctypes.c_ulonglong * (64 * 8 * 8))()
 l = _lib.lib()
 l.mcnerf_debug_stamps.restype = ctypes.c_int
 assert l.mcnerf_debug_stamps(buf) == 0
-t = np.frombuffer(buf, dtype=np.uint64).reshape(64, 4, 8).astype(np.int64)
-names = ["GEMM (incl. copy issue)", "wait at barrier 1", "epilogue", "wait at barrier 2"]
-dt = np.diff(t[:, :, :5], axis=2)
-ok = (t[:, :, 0] > 0)
-print(mode, "workgroups with stamps:", int(ok.all(1).sum()))
-for i, n in enumerate(names):
-    v = dt[:, :, i][ok]
-    print(f"  {n:26s} mean {v.mean():8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f} cycles (100 MHz ticks x?)")
-print("  layer total mean", (t[:, :, 4] - t[:, :, 0])[ok].mean())
+T = np.frombuffer(buf, dtype=np.uint64).reshape(64, 8, 8).astype(np.int64)
+for title, t, names in (("MFMA waves", T[:, :4], ["GEMM (incl. copy issue)", "wait at barrier 1", "epilogue", "wait at barrier 2"]),
+                        ("store waves", T[:, 4:], ["tile copy", "masks", "wait at barrier 1", "wait at barrier 2"])):
+    ok = (t[:, :, 0] > 0)
+    if not ok.any():
+        continue
+    dt = np.diff(t[:, :, :5], axis=2)
+    print(mode, title, "waves with stamps:", int(ok.sum()))
+    for i, n in enumerate(names):
+        v = dt[:, :, i][ok]
+        print(f"  {n:26s} mean {v.mean():8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f} cycles")
+    print("  layer total mean", (t[:, :, 4] - t[:, :, 0])[ok].mean())
+    if title == "MFMA waves" and (t[:, :, 7] > 0).any():
+        o2 = ok & (t[:, :, 7] > 0)
+        print(f"  tile: prologue+layers0-2 {(t[:, :, 0] - t[:, :, 5])[o2].mean():.0f}  layers 3..D-1 {(t[:, :, 6] - t[:, :, 0])[o2].mean():.0f}"
+              f"  heads+final {(t[:, :, 7] - t[:, :, 6])[o2].mean():.0f}  whole tile {(t[:, :, 7] - t[:, :, 5])[o2].mean():.0f}")
