@@ -168,6 +168,25 @@ __device__ __forceinline__ void mcn_zero(f32x16 (&acc)[NI][MI]) {
             for (int e = 0; e < 16; ++e) acc[ni][mi][e] = 0.f;
 }
 
+// sin and cos of an fp32 angle up to a few thousand radians (positions x 2^9), accurate to ~2e-7 absolute.
+// The library sincosf spends ~1500 cycles per call on such arguments (Payne-Hanek reduction); here the reduction
+// runs in fp64 -- v / 2pi, nearest integer, nearest quarter turn -- which leaves |phi| <= pi/4 exact to 1e-16, and
+// the kernels are the classic fp32 minimax polynomials on that interval (~40 instructions in all).
+__device__ __forceinline__ void mcn_sincos(float v, float& s, float& c) {
+    const double t = (double)v * 0.15915494309189535;         // turns
+    const double fr = t - __builtin_rint(t);                   // [-0.5, 0.5]
+    const double q = __builtin_rint(4.0 * fr);                 // nearest quarter turn: -2 .. 2
+    const float phi = (float)((fr - 0.25 * q) * 6.283185307179586);   // [-pi/4, pi/4]
+    const float z = phi * phi;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, phi, phi);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                          fmaf(-0.5f, z, 1.0f));
+    const int qi = (int)q & 3;                                 // two's complement: -1 -> 3, -2 -> 2
+    const float a = (qi & 1) ? cp : sp, b = (qi & 1) ? sp : cp;
+    s = (qi & 2) ? -a : a;                                     // q=0: (s, c)  1: (c, -s)  2: (-s, -c)  3: (-c, s)
+    c = ((qi + 1) & 2) ? -b : b;
+}
+
 // The nine signed deg-2 SH basis factors of eval_sh (model/net_utils.py:154-169).
 __device__ __forceinline__ void mcn_sh_basis(float x, float y, float z, float (&b)[9]) {
     const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;

@@ -38,7 +38,7 @@ __device__ __forceinline__ void write_encoding(float* X, const float* sxyz, cons
         const int c = cf / 10, f = cf - c * 10;
         const float v = sxyz[m * 4 + c] * (float)(1 << f);     // exact: power-of-two scale
         float s, co;
-        sincosf(v, &s, &co);
+        mcn_sincos(v, s, co);
         const float w = barf_w[f];
         X[mcn_swz(m, 3 + c * 20 + f, XW)] = s * w;
         X[mcn_swz(m, 3 + c * 20 + 10 + f, XW)] = co * w;

@@ -13,8 +13,12 @@ extern "C" int mcnerf_debug_stamps(unsigned long long* host_out) {
 }
 #define MCN_STAMP_T(i) do { if (WIDTH == 256 && blockIdx.x >= 2048 && blockIdx.x < 2048 + 64 && lane == 0) \
         g_mcn_stamps[((blockIdx.x - 2048) * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#if MCN_STAMPS == 2     // variant 2: slots 0..4 = end of layers 0..4 (after barrier 2), 5 = start, 6 = setup done, 7 = encoding done
+#define MCN_STAMP(i) do { if ((i) == 4 && l <= 4) MCN_STAMP_T(l); } while (0)
+#else
 #define MCN_STAMP(i) do { if (WIDTH == 256 && l == 3 && blockIdx.x >= 2048 && blockIdx.x < 2048 + 64 && lane == 0) \
         g_mcn_stamps[((blockIdx.x - 2048) * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#endif
 #else
 #define MCN_STAMP(i) do { } while (0)
 #define MCN_STAMP_T(i) do { } while (0)
@@ -52,7 +56,7 @@ __device__ __forceinline__ void write_encoding_h(_Float16* Xh, _Float16* Xl, con
         const int c = cf / 10, f = cf - c * 10;
         const float v = sxyz[m * 4 + c] * (float)(1 << f);     // exact: power-of-two scale
         float s, co;
-        sincosf(v, &s, &co);
+        mcn_sincos(v, s, co);
         const float w = barf_w[f];
         put(m, 3 + c * 20 + f, s * w);
         put(m, 3 + c * 20 + 10 + f, co * w);
@@ -211,8 +215,14 @@ __device__ __forceinline__ void mlp_fwd_h_body(const McnMlpFwdArgs& a) {
         saddr[m] = addr;
     }
     __syncthreads();
+#if defined(MCN_STAMPS) && MCN_STAMPS == 2
+    MCN_STAMP_T(6);
+#endif
     write_encoding_h<MT, XW>(Xh, Xl, sxyz, a.barf_w, tid, NT);
     __syncthreads();
+#if defined(MCN_STAMPS) && MCN_STAMPS == 2
+    MCN_STAMP_T(7);
+#endif
 
     f32x16 acc[NI][MI];
     // ---- trunk
@@ -251,7 +261,9 @@ __device__ __forceinline__ void mlp_fwd_h_body(const McnMlpFwdArgs& a) {
         MCN_STAMP(4);
     }
 
+#if !(defined(MCN_STAMPS) && MCN_STAMPS == 2)
     MCN_STAMP_T(6);
+#endif
     // ---- sigma head: hidden layer on MFMA, the 1-wide output layer lane-local on the VALU
     {
         mcn_zero<NI, MI>(acc);
@@ -322,7 +334,9 @@ __device__ __forceinline__ void mlp_fwd_h_body(const McnMlpFwdArgs& a) {
             for (int i = 0; i < MCN_NSH; ++i) dst[i] = sh[i];
         }
     }
+#if !(defined(MCN_STAMPS) && MCN_STAMPS == 2)
     MCN_STAMP_T(7);
+#endif
 }
 
 template <int WIDTH, bool SAVE>
