@@ -520,6 +520,14 @@ __global__ __launch_bounds__(512) void dw_h_kernel_v1(DwSeg s, const int* count,
 #pragma unroll
             for (int i = 0; i < NP; ++i) piece(i, base + 3 * RS, lds + ((cur + 3) & 3) * slab);
         }
+        if (base + RS > r1) {
+            // the chunk's last, partial slab: rows at or past r1 must contribute nothing.  The DMA clamped their
+            // addresses to the last valid row (finite X); their dY words are zeroed in LDS here (a per-lane select
+            // in registers would cost 28 v_cndmask in EVERY slab).
+            unsigned* z = reinterpret_cast<unsigned*>(lds) + cur * slab;
+            for (int it = (r1 - base) * N + tid; it < RS * N; it += 512) z[it] = 0u;
+            __syncthreads();
+        }
         if ((sidx % MS) == ms) {                                   // wave-uniform
             const float* sY = lds + cur * slab;
             const float* sX = sY + RS * N;
@@ -530,12 +538,10 @@ __global__ __launch_bounds__(512) void dw_h_kernel_v1(DwSeg s, const int* count,
             const unsigned* wX = reinterpret_cast<const unsigned*>(sX);
             UV av[8];
             unsigned bv[KT][8];
-            const bool tail = base + RS > r1;                      // only the chunk's last slab can hold rows past r1
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int row = 8 * h + j;
                 av[j] = *reinterpret_cast<const UV*>(wY + row * N + nbase + VN * r);
-                if (tail && base + row >= r1) av[j] = UV(0u);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) bv[kt][j] = wX[row * K + kbase + 32 * kt + r];
             }
