@@ -314,7 +314,7 @@ __device__ __forceinline__ void mlp_bwd_h_body(const McnMlpBwdArgs& a) {
 }
 
 template <int WIDTH>
-__global__ __launch_bounds__(McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>::WM * 64, McnGeomH<WIDTH>::WGS)
+__global__ __launch_bounds__(McnGeomH<WIDTH>::WN * McnGeomH<WIDTH>::WM * 64, McnGeomH<WIDTH>::WGS_BWD)
 void mlp_bwd_h_kernel(McnMlpBwdArgs a) { mlp_bwd_h_body<WIDTH, false>(a); }
 
 #if MCN_HELP_WGS == 2
