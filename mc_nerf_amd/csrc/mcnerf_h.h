@@ -33,12 +33,15 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // Tile geometry of the split-f16 forward / backward chains (defaults = McnGeom).  MCN_H_WM256 = 2 gives the 256-wide
 // net 128-row tiles on 8 waves, one workgroup per CU: the two waves that share an output slice fetch the same packed
 // weight fragments, so the L2 -> CU weight stream per sample halves.
+#ifndef MCN_WGS128
+#define MCN_WGS128 3
+#endif
 #ifndef MCN_H_WM256
 #define MCN_H_WM256 1
 #endif
 template <int WIDTH> struct McnGeomH : McnGeom<WIDTH> { static constexpr int WGS = 2, WGS_BWD = 2; };
 // 128-wide nets: the backward chain fits 168 registers, i.e. three workgroups (12 waves) per CU
-template <> struct McnGeomH<128> : McnGeom<128> { static constexpr int WGS = 2, WGS_BWD = 3; };
+template <> struct McnGeomH<128> : McnGeom<128> { static constexpr int WGS = MCN_WGS128, WGS_BWD = 3; };
 template <> struct McnGeomH<256> { static constexpr int WN = 4, NI = 2, WM = MCN_H_WM256, MI = 2, WGS = 2 / MCN_H_WM256, WGS_BWD = WGS; };
 #ifndef MCN_GEMM_UNROLL     // k-loop unrolling of mcn_gemm_seg_h: 0 = compiler's choice (full), 1 = rolled, n = by n
 #define MCN_GEMM_UNROLL 0
