@@ -33,6 +33,11 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // Tile geometry of the split-f16 forward / backward chains (defaults = McnGeom).  MCN_H_WM256 = 2 gives the 256-wide
 // net 128-row tiles on 8 waves, one workgroup per CU: the two waves that share an output slice fetch the same packed
 // weight fragments, so the L2 -> CU weight stream per sample halves.
+// workspace rows are written once and read by a later kernel: non-temporal stores keep them from evicting the packed
+// weights (re-read by every workgroup) from the L2
+#ifndef MCN_NT_STORES
+#define MCN_NT_STORES 1
+#endif
 #ifndef MCN_WGS128
 #define MCN_WGS128 3
 #endif
@@ -242,7 +247,11 @@ __device__ __forceinline__ void mcn_copy_tile_words(const _Float16* Xh, const _F
 #if defined(ABL_NOSTORE)
                 if (total < 0)
 #endif
+#if MCN_NT_STORES
+                __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst + (size_t)(row0 + m) * COLS + n4));
+#else
                 *reinterpret_cast<u32x4*>(dst + (size_t)(row0 + m) * COLS + n4) = w;
+#endif
             }
         }
     } else {

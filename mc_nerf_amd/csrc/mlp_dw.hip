@@ -18,6 +18,10 @@ struct DwSeg {
     float* db;                    // bias gradient or null
 };
 
+// cache policy of the operand stream (LDS-DMA aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1): the rows are read once
+#ifndef MCN_DW_AUX
+#define MCN_DW_AUX 2
+#endif
 #define DW_SLAB_ROWS 16
 template <int V> struct VecT;
 template <> struct VecT<1> { typedef float T; };
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(512) void dw_kernel(DwSeg s, const int* count, int 
             const int rc = grow < r1 ? grow : r1 - 1;
             const float* src = isY ? gY + (size_t)rc * ldy + 4 * c4 : gX + (size_t)rc * ldx + 4 * c4;
             float* dst = buf + 4 * (i * 512 + (tid & ~63));                // wave-uniform; the lane offset is implicit
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, MCN_DW_AUX);
         }
     };
     // All VMEM operations of the main loop are these pieces, NP per slab per wave, in program order, so
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(64 * dwh_waves(N, K)) void dw_h_kernel(DwSeg s, con
                 if ((i + 1) * NT <= tot4 || tid + i * NT < tot4) {
                     const float* src = !REG ? srcp[i < NPTR ? i : 0]
                                      : (i < NPY ? srcp[0] + (size_t)(i * (NT / n4)) * ldy : srcp[1] + (size_t)((i - NPY) * (NT / k4)) * ldx);
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(buf + 4 * (i * NT + (tid & ~63))), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(buf + 4 * (i * NT + (tid & ~63))), 16, 0, MCN_DW_AUX);
                 }
         } else {
             // (rare path, the chunk's last slabs: its address arithmetic is tied to this point by laundering tid,
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(64 * dwh_waves(N, K)) void dw_h_kernel(DwSeg s, con
                     const int row = qq / w4, c4 = qq - row * w4;
                     const int rc = min(base_row + row, r1 - 1);
                     const float* src = isY ? gY + (size_t)rc * ldy + 4 * c4 : gX + (size_t)rc * ldx + 4 * c4;
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(buf + 4 * (i * NT + (tid & ~63))), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(buf + 4 * (i * NT + (tid & ~63))), 16, 0, MCN_DW_AUX);
                 }
             }
         }
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(512) void dw_h_kernel_v1(DwSeg s, const int* count,
             const int rc = grow < r1 ? grow : r1 - 1;
             const float* src = isY ? gY + (size_t)rc * ldy + 4 * c4 : gX + (size_t)rc * ldx + 4 * c4;
             float* dst = buf + 4 * (i * 512 + (tid & ~63));
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, MCN_DW_AUX);
         }
     };
     // k slabs may stay in flight; the trailing waves issue NP-1 pieces per slab when tot4 % 512 != 0 (wave-uniform)
