@@ -279,10 +279,9 @@ __device__ __forceinline__ void dwh_consume(f32x16 (&acc)[VN][KT], float (&bsum)
     }
 }
 
-// WAVES = 4 (one wave per SIMD, 512 registers each) for the 256 x 256 segments: a 128 x 128 wave tile halves the
-// fragment-building VALU work and the LDS reads per MFMA and leaves the accumulators (256 registers) unspilled;
-// 8 waves for the smaller shapes.
-constexpr int dwh_waves(int N, int K) { return (N >= 256 && K >= 256) ? 4 : 8; }
+// waves per workgroup (a 4-wave, 128 x 128-tile variant for the 256 x 256 segments spilled next to its 256 accumulator
+// registers and was slower; those segments use dw_h_kernel_v1 below)
+constexpr int dwh_waves(int, int) { return 8; }
 
 template <int N, int K>
 __global__ __launch_bounds__(64 * dwh_waves(N, K)) void dw_h_kernel(DwSeg s, const int* count, int rows_cap, const unsigned int* gmax_bits) {
@@ -614,50 +613,45 @@ static int dw_num_cus() {
     return cus;
 }
 
+template <class Kern, class... Args>
+static hipError_t dw_launch(Kern kern, int grid, int threads, size_t lds, hipStream_t st, Args... args) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, args...);
+    return hipGetLastError();
+}
+
+// one segment: exact-fp32 kernel, or the split-f16 kernel for its shape (256 x 256: first formulation, see above)
+template <int NN, int KK>
+static hipError_t launch_seg_t(const DwSeg& s, const int* count, int rows_cap, int grid, size_t lds, hipStream_t st,
+                               const unsigned int* gmax_bits, bool split16) {
+    if (!split16) return dw_launch(dw_kernel<NN, KK>, grid, 512, lds, st, s, count, rows_cap);
+    if constexpr (NN >= 256 && KK >= 256) return dw_launch(dw_h_kernel_v1<NN, KK>, grid, 512, lds, st, s, count, rows_cap, gmax_bits);
+    else return dw_launch(dw_h_kernel<NN, KK>, grid, 64 * dwh_waves(NN, KK), lds, st, s, count, rows_cap, gmax_bits);
+}
+
 static hipError_t launch_seg(const DwSeg& s, const int* count, int rows_cap, hipStream_t st, const unsigned int* gmax_bits = nullptr, bool split16 = false) {
     if (rows_cap <= 0) return hipSuccess;
     int grid = dw_num_cus();                                   // persistent: one workgroup per CU
     const int max_wgs = (rows_cap + DW_SLAB_ROWS - 1) / DW_SLAB_ROWS;
     if (grid > max_wgs) grid = max_wgs;
     const size_t lds = (size_t)(split16 ? 4 : 3) * DW_SLAB_ROWS * (s.N + s.K) * sizeof(float);
-#define DW_LAUNCH(NN, KK) do { \
-        if (split16 && NN >= 256 && KK >= 256) { \
-            auto kern = dw_h_kernel_v1<NN, KK>; \
-            if (lds > 64 * 1024) { \
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                if (e != hipSuccess) return e; \
-            } \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, s, count, rows_cap, gmax_bits); \
-        } else if (split16) { \
-            auto kern = dw_h_kernel<NN, KK>; \
-            if (lds > 64 * 1024) { \
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                if (e != hipSuccess) return e; \
-            } \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * dwh_waves(NN, KK)), lds, st, s, count, rows_cap, gmax_bits); \
-        } else { \
-            auto kern = dw_kernel<NN, KK>; \
-            if (lds > 64 * 1024) { \
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                if (e != hipSuccess) return e; \
-            } \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, s, count, rows_cap); \
-        } } while (0)
-    const int key = s.N * 1000 + s.K;
-    switch (key) {
-        case 256256: DW_LAUNCH(256, 256); break;
-        case 256064: DW_LAUNCH(256, 64); break;
-        case 32256:  DW_LAUNCH(32, 256); break;
-        case 128128: DW_LAUNCH(128, 128); break;
-        case 128064: DW_LAUNCH(128, 64); break;
-        case 32128:  DW_LAUNCH(32, 128); break;
-        case 64064:  DW_LAUNCH(64, 64); break;
-        case 32064:  DW_LAUNCH(32, 64); break;
-        case 32032:  DW_LAUNCH(32, 32); break;
+#define DW_LAUNCH(NN, KK) return launch_seg_t<NN, KK>(s, count, rows_cap, grid, lds, st, gmax_bits, split16)
+    switch (s.N * 1000 + s.K) {
+        case 256256: DW_LAUNCH(256, 256);
+        case 256064: DW_LAUNCH(256, 64);
+        case 32256:  DW_LAUNCH(32, 256);
+        case 128128: DW_LAUNCH(128, 128);
+        case 128064: DW_LAUNCH(128, 64);
+        case 32128:  DW_LAUNCH(32, 128);
+        case 64064:  DW_LAUNCH(64, 64);
+        case 32064:  DW_LAUNCH(32, 64);
+        case 32032:  DW_LAUNCH(32, 32);
         default: return hipErrorInvalidValue;
     }
 #undef DW_LAUNCH
-    return hipGetLastError();
 }
 
 hipError_t mcn_launch_dw(const McnDwArgs& a, hipStream_t st) {
