@@ -386,3 +386,36 @@ def test_ragged_small_batches_match_oracle(gpu_device, n, precision):
     assert err(c, r["rgb_c"].detach().numpy()) < TOL and err(f, r["rgb_f"].detach().numpy()) < TOL
     k = int(m.last_selection[1].item())
     assert k == r["idx_f"].shape[0] and torch.equal(m.last_selection[0][:k].cpu().long(), r["idx_f"])
+
+
+@pytest.mark.parametrize("white_back", [True, False])
+@pytest.mark.parametrize("step_r", [0.0, 0.45, 1.0])
+def test_background_and_barf_schedule_extremes(gpu_device, white_back, step_r):
+    """white_back on/off and the BARF mask before / inside / after its window (all frequencies off, partly on, all on),
+    train render + loss gradients of both nets against the CPU oracle (small nets, oracle in seconds)."""
+    import dataclasses
+    dev = gpu_device
+    cfg = O.RenderCfg(samples=32, scale=2, coarse=O.NetCfg(4, 32, (2,)), fine=O.NetCfg(8, 64, (4,)), white_back=white_back,
+                      barf_mode=True, barf_start=0.3, barf_end=0.6)
+    from mc_nerf_amd.model import NeRF_Model, MC_NeRF_Loss
+    m = NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0)).to(dev)
+    m.emmbedding_xyz.barf_mode = True
+    pc = {k: v.requires_grad_(True) for k, v in O.init_params(cfg.coarse, 31).items()}
+    pf = {k: v.requires_grad_(True) for k, v in O.init_params(cfg.fine, 32).items()}
+    m.nerf_coarse.load_state_dict({k: v.detach() for k, v in pc.items()})
+    m.nerf_fine.load_state_dict({k: v.detach() for k, v in pf.items()})
+    n = 96
+    d, o, kw = _full_size_inputs(n, cfg, torch.device("cpu"), seed=77)
+    gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(1))
+    r = O.render_rays_train(pc, pf, cfg, d, o, step_r, kw["jitter"], kw["eps_c"], kw["eps_sel"], kw["eps_f"])
+    O.rgb_loss(r["rgb_c"], r["rgb_f"], gt).backward()
+    c, f = m.render_rays_train(d.to(dev), o.to(dev), 0, step_r, **{k: v.to(dev) for k, v in kw.items()})
+    assert err(c, r["rgb_c"].detach().numpy()) < TOL and err(f, r["rgb_f"].detach().numpy()) < TOL
+    MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([c, f, gt.to(dev)]).backward()
+    for net, ref in ((m.nerf_coarse, pc), (m.nerf_fine, pf)):
+        for k, p in net.named_parameters():
+            g = ref[k].grad
+            if g is None:
+                g = torch.zeros_like(ref[k])
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            assert err(got, g.numpy()) < 1e-4 * max(1.0, float(g.abs().max())), k
