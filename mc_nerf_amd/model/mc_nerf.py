@@ -133,6 +133,58 @@ class NeRF_Model(nn.Module):
         return render_test(self, model_coarse, model_fine, rays_d.float(), rays_o.float(),
                            self._dev(eps_c).contiguous(), self._dev(eps_sel).contiguous(), self._dev(eps_f).contiguous())
 
+    # ------------------------------------------------------------------ per-pass API of the reference (:682-736)
+    @torch.no_grad()
+    def inference(self, model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render=None, coarse=True, *, eps=None):
+        """One pass of one net on given samples -> (rgb [N,3], sigmas [N,S], xyz, depth [N,1], opacity [N,1]), the
+        reference's `inference` (:682-727) for callers that use it directly.
+
+        The HIP kernels generate the positions themselves from (origin, direction, z grid + per-ray jitter), so
+        `z_vals` must have the reference's structure (its own call sites always do): `z_vals[n, j] = grid[j] + jitter[n]`
+        with `grid` this model's coarse or fine grid; the origins are recovered from `xyz[:, 0]`.  Forward only: training
+        differentiates through the fused `render_rays_train`.  `eps` is the N(0,1) draw of `sigma2weights` (drawn from
+        the device generator when not given)."""
+        N, S_ = z_vals.shape
+        dev = rays_d.device
+        grid = self.z_vals_c if S_ == self.samples_c else self.z_vals_f
+        if S_ not in (self.samples_c, self.samples_f):
+            raise NotImplementedError("inference(): z_vals must be this model's coarse or fine grid (+ per-ray jitter)")
+        z_vals = z_vals.float()
+        jitter = (z_vals[:, 0] - grid[0]).contiguous()
+        if not torch.allclose(z_vals, grid.unsqueeze(0) + jitter.unsqueeze(1), atol=1e-5, rtol=0):
+            raise NotImplementedError("inference(): z_vals is not grid + per-ray jitter")
+        rays_d = rays_d.float().contiguous()
+        rays_o = (xyz.reshape(N, S_, 3)[:, 0].float() - rays_d * z_vals[:, :1]).contiguous()
+        st = self.settings
+        flat = model.flat_params()
+        packed = ops.pack_weights(model.net, flat, precision=st.precision)
+        barf_w = embedding_xyz.barf_weights(step_r).to(dev)
+        if idx_render is None:
+            out = torch.empty(N, S_, 4, dtype=torch.float32, device=dev)
+            ops.mlp_fwd(model.net, flat, packed, rays_o, rays_d, grid, jitter, barf_w, out, precision=st.precision)
+        else:                                                   # scatter into the defaults (:692-694, 701)
+            out = torch.ones(N, S_, 4, dtype=torch.float32, device=dev)
+            out[..., 0] = st.sigma_default
+            idx = idx_render.to(device=dev, dtype=torch.int32).contiguous()
+            count = torch.tensor([idx.shape[0]], dtype=torch.int32, device=dev)
+            ops.mlp_fwd(model.net, flat, packed, rays_o, rays_d, grid, jitter, barf_w, out, idx=idx, count=count,
+                        max_rows=idx.shape[0], precision=st.precision)
+        if eps is None:
+            eps = torch.randn(N, S_, device=dev)
+        rgb, depth, opacity, _, _ = ops.composite_fwd(out, rays_d, grid, jitter, self._dev(eps).float().contiguous(), None,
+                                                      st.white_back, want_depth=True)
+        return rgb, out[..., 0], xyz, depth, opacity
+
+    @staticmethod
+    def sigma2weights(deltas, sigmas, eps=None):
+        """Reference :729-736 on arbitrary `deltas` (compatibility helper in plain tensor ops; the render path computes the
+        same weights inside the fused composite kernels)."""
+        if eps is None:
+            eps = torch.randn_like(sigmas)
+        alphas = 1.0 - torch.exp(-deltas * torch.nn.functional.softplus(sigmas + eps))
+        shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1.0 - alphas + 1e-10], -1)
+        return alphas * torch.cumprod(shifted, -1)[:, :-1]
+
     # ------------------------------------------------------------------ checkpoints (:738-752, 815-837)
     def save_model(self, model, epoch):
         save_path = os.path.join(Path(self.weights_pth), Path("train"))

@@ -419,3 +419,34 @@ def test_background_and_barf_schedule_extremes(gpu_device, white_back, step_r):
                 g = torch.zeros_like(ref[k])
             got = p.grad if p.grad is not None else torch.zeros_like(p)
             assert err(got, g.numpy()) < 1e-4 * max(1.0, float(g.abs().max())), k
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_inference_and_sigma2weights_api(gpu_device, precision):
+    """The reference's per-pass API (NeRF_Model.inference :682-727, sigma2weights :729-736) against the oracle: coarse
+    pass on the dense grid and fine pass on an index list, with the reference's z_vals = grid + per-ray jitter."""
+    dev = gpu_device
+    cfg = O.RenderCfg(samples=32, scale=2, coarse=O.NetCfg(4, 32, (2,)), fine=O.NetCfg(8, 64, (4,)))
+    from mc_nerf_amd.model import NeRF_Model
+    m = NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision=precision)).to(dev)
+    pc, pf = O.init_params(cfg.coarse, 41), O.init_params(cfg.fine, 42)
+    m.nerf_coarse.load_state_dict(pc)
+    m.nerf_fine.load_state_dict(pf)
+    n = 45
+    d, o, kw = _full_size_inputs(n, cfg, torch.device("cpu"), seed=5)
+    zc, zf = O._grids(cfg)
+    for grid, p, net, model, eps, coarse in ((zc, pc, cfg.coarse, m.nerf_coarse, kw["eps_c"], True),
+                                            (zf, pf, cfg.fine, m.nerf_fine, kw["eps_f"], False)):
+        z = grid.unsqueeze(0) + kw["jitter"]
+        xyz = o.unsqueeze(1) + d.unsqueeze(1) * z.unsqueeze(2)
+        idx = None if coarse else torch.nonzero(torch.rand(n, z.shape[1], generator=torch.Generator().manual_seed(1)) < 0.4)
+        rgb, sig, depth, opac, _ = O.inference(p, net, cfg, 1.0, o, d, z, eps, idx)
+        got = m.inference(model, m.emmbedding_xyz, 1.0, xyz.to(dev), d.to(dev), z.to(dev),
+                          None if idx is None else idx.to(dev), coarse, eps=eps.to(dev))
+        assert err(got[0], rgb.numpy()) < TOL and err(got[3], depth.numpy()) < TOL and err(got[4], opac.numpy()) < TOL
+        assert err(got[1], sig.numpy()) < 1e-4 * max(1.0, float(sig.abs().max()))
+        assert got[2].shape == xyz.shape
+    dl, sg, ep = torch.rand(7, 16) + 0.05, torch.randn(7, 16) * 3, torch.randn(7, 16)
+    assert err(m.sigma2weights(dl.to(dev), sg.to(dev), ep.to(dev)), O.sigma2weights(dl, sg, ep).numpy()) < 2e-6
+    with pytest.raises(NotImplementedError):
+        m.inference(m.nerf_coarse, m.emmbedding_xyz, 1.0, xyz.to(dev)[:, :7], d.to(dev), torch.rand(n, 7, device=dev))
