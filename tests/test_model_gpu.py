@@ -450,3 +450,28 @@ def test_inference_and_sigma2weights_api(gpu_device, precision):
     assert err(m.sigma2weights(dl.to(dev), sg.to(dev), ep.to(dev)), O.sigma2weights(dl, sg, ep).numpy()) < 2e-6
     with pytest.raises(NotImplementedError):
         m.inference(m.nerf_coarse, m.emmbedding_xyz, 1.0, xyz.to(dev)[:, :7], d.to(dev), torch.rand(n, 7, device=dev))
+
+
+def test_full_size_precision_modes_agree(gpu_device):
+    """Bench configuration, 16384 rays: the split-f16 mode against the exact-fp32 mode on identical inputs -- rendered
+    colours within the 1e-4 bar, identical fine-sample selection, and whole-gradient agreement (relative L2) per net."""
+    dev = gpu_device
+    n = 16384
+    res = {}
+    for precision in ("f32", "f16x3"):
+        m, cfg = _full_size_model(dev, precision)
+        d, o, kw = _full_size_inputs(n, cfg, dev, seed=23)
+        gt = torch.rand(n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+        from mc_nerf_amd.model import MC_NeRF_Loss
+        c, f = m.render_rays_train(d, o, 0, 0.5, **kw)
+        MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([c, f, gt]).backward()
+        k = int(m.last_selection[1].item())
+        res[precision] = (c.detach(), f.detach(), m.last_selection[0][:k].clone(),
+                          torch.cat([p.grad.reshape(-1) for p in m.nerf_coarse.parameters()]),
+                          torch.cat([p.grad.reshape(-1) for p in m.nerf_fine.parameters()]))
+    a, b = res["f32"], res["f16x3"]
+    assert float((a[0] - b[0]).abs().max()) < TOL and float((a[1] - b[1]).abs().max()) < TOL
+    assert torch.equal(a[2], b[2])
+    for i, name in ((3, "coarse"), (4, "fine")):
+        rel = float((a[i].double() - b[i].double()).norm() / a[i].double().norm())
+        assert rel < 1e-4, f"{name} gradient: relative L2 difference {rel:.3e}"
