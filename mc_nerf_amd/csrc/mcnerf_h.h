@@ -83,6 +83,11 @@ struct McnNoPre { __device__ __forceinline__ void operator()() const {} };
 template <int XW, int NI, int MI, class Side = McnNoSide, class Pre = McnNoPre>
 __device__ __forceinline__ void mcn_gemm_seg_h(f32x16 (&acc)[NI][MI], const _Float16* Xh, const _Float16* Xl, int mrow0,
                                                int kchunk0, int KS16, const h8* __restrict__ P, int lane, Side side = Side(), Pre pre = Pre()) {
+#ifdef ABL_NOGEMM      // (ablation: no matrix work at all -- what do the workspace streams alone cost?)
+    pre();
+    for (int ks = 0; ks < KS16; ++ks) side(ks);
+    return;
+#endif
     const int r = lane & 31, h = lane >> 5;
     constexpr int SWZ = (XW / 8 - 1) < 15 ? (XW / 8 - 1) : 15;
     const int sw = (mrow0 + r) & SWZ;
