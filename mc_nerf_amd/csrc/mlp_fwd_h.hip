@@ -92,19 +92,30 @@ __device__ __forceinline__ void layer_epilogue_h(f32x16 (&acc)[NI][MI], const fl
                 const int n4 = ncol0 + ni * 32 + 8 * q + 4 * h;
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n4);
                 f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaxf(acc[ni][mi][4 * q + e] * (1.0f / (MCN_SW * MCN_SX)) + bb[e], 0.f);
-                    if (MASKS) bits |= (v[e] > 0.f ? 1u : 0u) << (8 * q + 4 * h + e);
-                }
-                if (DOT) {
-                    const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + n4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dot[mi] = fmaf(v[e], ww[e], dot[mi]);
-                }
                 u32x4 w;
-                if (TO_LDS) w = mcn_store_split4<(WIDTH > 64 ? WIDTH : 64)>(Xh, Xl, m, n4, v);
-                else if (SAVE) w = mcn_words4(v, MCN_SX);
+                if (TO_LDS && !DOT) {
+                    // straight into the activation scale: relu(acc / SW + SX * b) == SX * relu(acc / (SW * SX) + b) bit for
+                    // bit (power-of-two scales commute with rounding); one fma per value instead of mul, add and mul
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaxf(fmaf(acc[ni][mi][4 * q + e], 1.0f / MCN_SW, bb[e] * MCN_SX), 0.f);
+                        if (MASKS) bits |= (v[e] > 0.f ? 1u : 0u) << (8 * q + 4 * h + e);
+                    }
+                    w = mcn_store_split4<(WIDTH > 64 ? WIDTH : 64)>(Xh, Xl, m, n4, v, 1.0f);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaxf(acc[ni][mi][4 * q + e] * (1.0f / (MCN_SW * MCN_SX)) + bb[e], 0.f);
+                        if (MASKS) bits |= (v[e] > 0.f ? 1u : 0u) << (8 * q + 4 * h + e);
+                    }
+                    if (DOT) {
+                        const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + n4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dot[mi] = fmaf(v[e], ww[e], dot[mi]);
+                    }
+                    if (TO_LDS) w = mcn_store_split4<(WIDTH > 64 ? WIDTH : 64)>(Xh, Xl, m, n4, v);
+                    else if (SAVE) w = mcn_words4(v, MCN_SX);
+                }
                 // (layers that go to the LDS tile are saved from there, row-coalesced: mcn_copy_tile_words)
                 if (SAVE && !TO_LDS && ok) *reinterpret_cast<u32x4*>(save + (size_t)(row0 + m) * WIDTH + n4) = w;     // split words
             }
