@@ -14,15 +14,22 @@ loss_fn = MC_NeRF_Loss(sp); opt = RAdam(model.parameters(), lr=5e-4, weight_deca
 sync = D.FlatGradSync(model, 1)
 wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0]); wpts, pts = wpts.to(dev), pts.to(dev)
 images = DeviceImageSet.synthetic(110, 800, 800, dev)
-for i in range(6):
-    data = (images, torch.tensor([i]), wpts, pts, wpts, pts)
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+bad_steps = 0
+for i in range(STEPS):
+    data = (images, torch.tensor([i % 110]), wpts, pts, wpts, pts)
     ld, *_ = model(data, 20, "GLOBAL_OPTIM_EPOCH", 0.6)
     loss = loss_fn(ld, "GLOBAL_OPTIM_EPOCH")
     opt.zero_grad(set_to_none=True); sync.prepare(); loss.backward(); sync.sync()
     g = sync.arena
     k = int(model.nerf.last_selection[1].item())
-    print(f"step {i}: loss {float(loss.detach()):.5f} K/ray {k/N:.1f} grad finite {bool(torch.isfinite(g).all())} |g|max {float(g.abs().max()):.3e} "
+    fin = bool(torch.isfinite(g).all())
+    bad_steps += 0 if fin else 1
+    if STEPS <= 12 or i % 25 == 0 or not fin:
+      print(f"step {i}: loss {float(loss.detach()):.5f} K/ray {k/N:.1f} grad finite {bool(torch.isfinite(g).all())} |g|max {float(g.abs().max()):.3e} "
           f"nan params {sum(int((~torch.isfinite(p)).sum()) for p in model.parameters())}")
     bad = [(n, float(p.grad.abs().max())) for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
     if bad: print("   non-finite grads in:", bad[:6])
     opt.step()
+print(f"{STEPS} steps, steps with non-finite gradients: {bad_steps}, non-finite parameters at the end: "
+      f"{sum(int((~torch.isfinite(p)).sum()) for p in model.parameters())}")
