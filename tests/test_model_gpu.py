@@ -475,3 +475,28 @@ def test_full_size_precision_modes_agree(gpu_device):
     for i, name in ((3, "coarse"), (4, "fine")):
         rel = float((a[i].double() - b[i].double()).norm() / a[i].double().norm())
         assert rel < 1e-4, f"{name} gradient: relative L2 difference {rel:.3e}"
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_full_size_cap_path(gpu_device, precision):
+    """BASELINE configs[4]-like sampling (64 coarse + 256 fine grid, scale 4) on the full-size nets: more than 128 fine
+    samples per ray get selected at random init, so the training cap (model/mc_nerf.py:630-632) binds -- exactly
+    N * 128 samples are evaluated, through the host-synchronised permutation path, and the step stays finite."""
+    dev = gpu_device
+    from mc_nerf_amd.model import NeRF_Model, MC_NeRF_Loss
+    cfg = O.RenderCfg(samples=64, scale=4, coarse=O.NetCfg(4, 128, (2,)), fine=O.NetCfg(8, 256, (4,)))
+    m = NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision=precision)).to(dev)
+    m.nerf_coarse.load_state_dict(O.init_params(cfg.coarse, 3))
+    m.nerf_fine.load_state_dict(O.init_params(cfg.fine, 4))
+    n = 4096
+    d, o, kw = _full_size_inputs(n, cfg, dev, seed=29)
+    torch.manual_seed(0)                                       # the cap permutation comes from the CPU generator (:631)
+    c, f = m.render_rays_train(d, o, 0, 0.5, **kw)
+    k = int(m.last_selection[1].item())
+    assert k == n * 128, k
+    idx = m.last_selection[0][:k].long()
+    assert int(idx[:, 0].max()) < n and int(idx[:, 1].max()) < 256 and idx.min() >= 0
+    assert torch.unique(idx[:, 0] * 256 + idx[:, 1]).numel() == k          # a subset, no duplicates
+    MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([c, f, torch.rand(n, 3, device=dev)]).backward()
+    assert torch.isfinite(c).all() and torch.isfinite(f).all()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
