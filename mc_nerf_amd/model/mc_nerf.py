@@ -99,6 +99,9 @@ class NeRF_Model(nn.Module):
         (U(0,(far-near)/Sc) per ray; three N(0,1) tensors; the cap permutation); when omitted they are
         drawn from torch's device generator in the reference's order."""
         N, dev = rays_d.shape[0], rays_d.device
+        if N == 0:                                  # empty batch: empty results (the reference's tensor ops do the same)
+            e3, e1 = rays_d.new_zeros(0, 3), rays_d.new_zeros(0, 1)
+            return (e3, None, e1) if only_coarse else (e3, e3.clone())
         if jitter is None:
             jitter = torch.empty(N, 1, device=dev).uniform_(0.0, (self.far - self.near) / self.samples_c)
         if eps_c is None:
@@ -124,6 +127,8 @@ class NeRF_Model(nn.Module):
     def render_rays_test(self, rays_d, rays_o, model_coarse, model_fine, *, eps_c=None, eps_sel=None, eps_f=None):
         """Reference :648-680 (the nets are arguments because valid_train passes freshly loaded ones)."""
         N, dev = rays_d.shape[0], rays_d.device
+        if N == 0:
+            return rays_d.new_zeros(0, 3), rays_d.new_zeros(0, 1), rays_d.new_zeros(0, 1)
         if eps_c is None:
             eps_c = torch.randn(N, self.samples_c, device=dev)
         if eps_sel is None:

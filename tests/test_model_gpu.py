@@ -500,3 +500,20 @@ def test_full_size_cap_path(gpu_device, precision):
     MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([c, f, torch.rand(n, 3, device=dev)]).backward()
     assert torch.isfinite(c).all() and torch.isfinite(f).all()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_empty_and_single_ray_batches(gpu_device):
+    """N = 0 returns empty results (as the reference's tensor ops would), N = 1 renders and differentiates."""
+    dev = gpu_device
+    cfg = O.RenderCfg(samples=32, scale=2, coarse=O.NetCfg(4, 32, (2,)), fine=O.NetCfg(8, 64, (4,)))
+    from mc_nerf_amd.model import NeRF_Model
+    m = NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0)).to(dev)
+    e = torch.zeros(0, 3, device=dev)
+    c, f = m.render_rays_train(e, e, 0, 0.5)
+    assert c.shape == (0, 3) and f.shape == (0, 3)
+    r = m.render_rays_test(e, e, m.nerf_coarse, m.nerf_fine)
+    assert [tuple(t.shape) for t in r] == [(0, 3), (0, 1), (0, 1)]
+    d = torch.nn.functional.normalize(torch.randn(1, 3, device=dev), dim=-1).requires_grad_(True)
+    c, f = m.render_rays_train(d, torch.randn(1, 3, device=dev) * 3, 0, 0.5)
+    (c.sum() + f.sum()).backward()
+    assert c.shape == (1, 3) and torch.isfinite(d.grad).all()
