@@ -517,3 +517,13 @@ def test_empty_and_single_ray_batches(gpu_device):
     c, f = m.render_rays_train(d, torch.randn(1, 3, device=dev) * 3, 0, 0.5)
     (c.sum() + f.sum()).backward()
     assert c.shape == (1, 3) and torch.isfinite(d.grad).all()
+
+
+def test_randomised_configs_match_oracle(gpu_device):
+    """A fixed-seed slice of tests/parity_fuzz.py: 14 random configurations end to end against the oracle."""
+    import random
+    from parity_fuzz import one_case
+    rng = random.Random(2024)
+    res = [one_case(rng, gpu_device, verbose=False) for _ in range(14)]
+    assert not any(r is False for r in res)
+    assert sum(1 for r in res if r is True) >= 8
