@@ -26,7 +26,10 @@ def init_distributed(backend: Optional[str] = None):
     local = int(os.environ.get("LOCAL_RANK", rank))
     use_cuda = torch.cuda.is_available()
     if backend is None:
-        backend = "nccl" if use_cuda else "gloo"
+        backend = os.environ.get("MCNERF_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+    if use_cuda and os.environ.get("MCNERF_SHARE_GPU") == "1":
+        # test rigs with fewer GPUs than ranks (RCCL itself needs one GPU per rank: combine with MCNERF_DIST_BACKEND=gloo)
+        local %= torch.cuda.device_count()
     dev = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(dev)
