@@ -7,6 +7,17 @@
 #include "mcnerf_h.h"
 #include "mcnerf_kernels.h"
 
+#ifdef MCN_STAMPS      // (diagnostic build: in-kernel cycle stamps of the tile phases, read back by scripts/stamps_bwd.py)
+__device__ unsigned long long g_mcn_bstamps[64 * 4 * 8];
+extern "C" int mcnerf_debug_stamps_bwd(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mcn_bstamps), sizeof(g_mcn_bstamps));
+}
+#define MCN_BSTAMP(i) do { if (WIDTH == 256 && blockIdx.x >= 2048 && blockIdx.x < 2048 + 64 && lane == 0 && wave < 4) \
+        g_mcn_bstamps[((blockIdx.x - 2048) * 4 + wave) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MCN_BSTAMP(i) do { } while (0)
+#endif
+
 template <int WIDTH>
 struct BwdSmemH {
     using G = McnGeomH<WIDTH>;
@@ -128,6 +139,7 @@ __device__ __forceinline__ void mlp_bwd_h_body(const McnMlpBwdArgs& a) {
     const float sg = (gmax > 0.f && gmax < 3e38f) ? exp2f(4.f - ceilf(log2f(gmax))) : 1.f;
     const float inv = 1.0f / (MCN_SW * sg);
 
+    MCN_BSTAMP(0);
     // ---- per-sample prologue: sigmoid and SH backward -> dsh (the dY of sh.2), d sigma, d dir
     for (int m = tid; m < MT; m += NT) {
         const long long g = row0 + m;
@@ -179,6 +191,7 @@ __device__ __forceinline__ void mlp_bwd_h_body(const McnMlpBwdArgs& a) {
     }
     __syncthreads();
 
+    MCN_BSTAMP(1);
     f32x16 acc[NI][MI];
     // ---- sh.2^T : dsh [MT][32] -> d hc ; mask with hc -> dY of sh.0
     mcn_zero<NI, MI>(acc);
@@ -203,10 +216,19 @@ __device__ __forceinline__ void mlp_bwd_h_body(const McnMlpBwdArgs& a) {
         constexpr int MG = NT / W4;             // sample groups (threads / chunks per row)
         const int c4 = tid % W4, mg = tid / W4;
         const f32x4 ww = *reinterpret_cast<const f32x4*>(w2 + 4 * c4);
-        for (int m = mg; m < MT; m += MG) {
+        // all mask words of this thread's rows first (unconditional, clamped loads issued back to back): the row loop
+        // below otherwise pays one exposed HBM latency per row
+        unsigned wrow[MT / MG];
+#pragma unroll
+        for (int k = 0; k < MT / MG; ++k) {
+            const long long g = row0 + mg + k * MG;
+            wrow[k] = hm[(size_t)(g < total ? g : total - 1) * (WIDTH / 32) + (c4 >> 3)];
+        }
+#pragma unroll
+        for (int k = 0; k < MT / MG; ++k) {
+            const int m = mg + k * MG;
             const bool ok = row0 + m < total;
-            const long long gc = ok ? row0 + m : total - 1;
-            const unsigned w = hm[(size_t)gc * (WIDTH / 32) + (c4 >> 3)] >> (4 * (c4 & 7));
+            const unsigned w = wrow[k] >> (4 * (c4 & 7));
             const float ds = ok ? sdsig[m] : 0.f;
             f32x4 v;
 #pragma unroll
@@ -221,6 +243,7 @@ __device__ __forceinline__ void mlp_bwd_h_body(const McnMlpBwdArgs& a) {
     mask_store_h<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(D - 1) * (AS / 32), Xh, Xl, inv, sg, mrow0, ncol0, row0, total, lane);
     __syncthreads();
 
+    MCN_BSTAMP(2);
     // ---- trunk, last layer to first.  X holds dY_l; the encoded-input gradient accumulates in denc.
     f32x16 denc[1][1];
     mcn_zero<1, 1>(denc);
@@ -254,6 +277,7 @@ __device__ __forceinline__ void mlp_bwd_h_body(const McnMlpBwdArgs& a) {
         __syncthreads();
     }
     __syncthreads();
+    MCN_BSTAMP(3);
     // ---- encoded-input gradient -> LDS [MT][64]
     {
         const int r = lane & 31, h = lane >> 5;
@@ -273,6 +297,7 @@ __device__ __forceinline__ void mlp_bwd_h_body(const McnMlpBwdArgs& a) {
         }
     }
     __syncthreads();
+    MCN_BSTAMP(4);
     // ---- encoding backward -> d xyz -> d rays_o / d rays_d
     //   enc channel 3+20c+f = w_f sin(2^f x_c), 3+20c+10+f = w_f cos(2^f x_c)  (w_f already inside enc_save)
     if (a.d_rays_o || a.d_rays_d) {
@@ -311,6 +336,7 @@ __device__ __forceinline__ void mlp_bwd_h_body(const McnMlpBwdArgs& a) {
             }
         }
     }
+    MCN_BSTAMP(5);
 }
 
 template <int WIDTH>
