@@ -200,7 +200,7 @@ def main():
         # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes of this same command, collected and
         # corrected as MI355X_MICROARCH.md prescribes (scripts/pmc_traffic.py; see profiles/*_pmc_traffic.json)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json" if args.precision == "f16x3" else "r01c_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json" if args.precision == "f16x3" else "r01c_pmc_traffic.json")
         if os.path.exists(tpath) and args.rays == 32768:
             sfx = "_h" if args.precision == "f16x3" else ""
             names = {"mlp_fwd<256>": f"mlp_fwd{sfx}_kernel<256, true>", "mlp_bwd<256>": f"mlp_bwd{sfx}_kernel<256>"}
