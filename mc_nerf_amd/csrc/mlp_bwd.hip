@@ -110,7 +110,10 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             const float x = a.rays_d[ray * 3], y = a.rays_d[ray * 3 + 1], z = a.rays_d[ray * 3 + 2];
             float b[9];
             mcn_sh_basis(x, y, z, b);
-            const float* sh = a.sh_save + (size_t)g * MCN_NSHP;
+            __attribute__((aligned(16))) float sh[MCN_NSHP];                 // the saved SH row: 7 vector loads
+#pragma unroll
+            for (int i = 0; i < MCN_NSH + 1; i += 4)
+                *reinterpret_cast<f32x4*>(&sh[i]) = *reinterpret_cast<const f32x4*>(a.sh_save + (size_t)g * MCN_NSHP + i);
             const float C1 = 0.4886025119029199f, C20 = 1.0925484305920792f, C22 = 0.31539156525252005f,
                         C24 = 0.5462742152960396f;
 #pragma unroll

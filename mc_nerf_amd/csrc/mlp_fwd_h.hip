@@ -340,9 +340,14 @@ __device__ __forceinline__ void mlp_fwd_h_body(const McnMlpFwdArgs& a) {
         }
         *reinterpret_cast<f32x4*>(a.out + (size_t)saddr[m] * 4) = o;
         if (SAVE) {
-            float* dst = a.sh_save + (size_t)g * MCN_NSHP;
+            float* dst = a.sh_save + (size_t)g * MCN_NSHP;             // 128-byte row: 7 vector stores (column 27 is padding)
 #pragma unroll
-            for (int i = 0; i < MCN_NSH; ++i) dst[i] = sh[i];
+            for (int i = 0; i < MCN_NSH + 1; i += 4) {
+                f32x4 v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = i + e < MCN_NSH ? sh[i + e] : 0.f;
+                *reinterpret_cast<f32x4*>(dst + i) = v4;
+            }
         }
     }
 #if !(defined(MCN_STAMPS) && MCN_STAMPS == 2)
