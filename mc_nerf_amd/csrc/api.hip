@@ -2,6 +2,7 @@
 // kernel is enqueued on the caller's stream, nothing here synchronises or allocates.
 #include "../../include/mcnerf.h"
 #include "mcnerf_kernels.h"
+#include "mcnerf_16.h"
 #ifdef ABL_ALIAS     // (ablation build only: every workspace slot aliases slot 0 = same bytes moved, 1/10 of the footprint)
 #define MCN_ACT_STRIDE(capacity, width) ((size_t)0)
 #else
@@ -183,6 +184,81 @@ int mcnerf_mlp_dw_f16x3(int depth, int width, int skip, const int32_t* count, in
     a.count = count; a.rows = rows; a.act_save = act_save; a.enc_save = enc_save; a.dy_save = dy_save;
     a.dsh_save = dsh_save; a.act_stride = MCN_ACT_STRIDE(capacity, width); a.grads = grads; a.split16 = true; a.gmax_bits = gmax_bits;
     return check("mcnerf_mlp_dw_f16x3", mcn_launch_dw(a, (hipStream_t)stream));
+}
+
+// ---- single-pass 16-bit mode (mcnerf_16.h)
+long long mcnerf_packed_bytes_16(int depth, int width, int skip, int backward) {
+    if (!net_ok(depth, width, skip)) return -1;
+    const McnLayout L = mcn_make_layout(depth, width, skip);
+    return (long long)(backward ? mcn16_bwd_stream(L) : mcn16_fwd_stream(L)).total_frags * 1024;
+}
+int mcnerf_pack_weights_16(int depth, int width, int skip, const float* params, void* packed_fwd, void* packed_bwd,
+                           int dtype, void* stream) {
+    REQ(net_ok(depth, width, skip) && params && packed_fwd && packed_bwd && (dtype == 0 || dtype == 1), "mcnerf_pack_weights_16");
+    return check("mcnerf_pack_weights_16", mcn16_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, dtype, (hipStream_t)stream));
+}
+long long mcnerf_ws_bytes_16(int depth, int width, long long capacity, int which) {
+    if (!net_ok(depth, width, 0) || capacity < 0) return -1;
+    switch (which) {
+        case 0: return (long long)(depth + 2) * (long long)mcn16_slot_bytes(capacity, width);
+        case 1: return (long long)mcn16_enc_bytes(capacity);
+        case 2: return (long long)(depth + 2) * (long long)mcn16_mask_slot_bytes(capacity, width);
+        case 3: return (long long)mcn16_dsh_bytes(capacity);
+    }
+    return -1;
+}
+int mcnerf_mlp_fwd_16(int depth, int width, int skip, int dtype, const float* params, const void* packed_fwd,
+                      const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
+                      const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
+                      int n_rays, int S, float* out,
+                      void* act_ws, long long capacity, void* enc_ws, uint32_t* mask_ws, void* stream) {
+    REQ(net_ok(depth, width, skip) && (dtype == 0 || dtype == 1), "mcnerf_mlp_fwd_16");
+    REQ(params && packed_fwd && rays_o && rays_d && zgrid && barf_w && out && n_rays >= 0 && S > 0, "mcnerf_mlp_fwd_16");
+    REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_fwd_16");
+    REQ(!idx || max_rows >= 0, "mcnerf_mlp_fwd_16");
+    REQ((long long)n_rays * S < (1ll << 31), "mcnerf_mlp_fwd_16");
+    REQ((act_ws == nullptr) == (enc_ws == nullptr) && (act_ws == nullptr) == (mask_ws == nullptr), "mcnerf_mlp_fwd_16");
+    if (act_ws) REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_fwd_16");
+    Mcn16FwdArgs a;
+    a.lay = mcn_make_layout(depth, width, skip);
+    a.params = params; a.packed = packed_fwd; a.stream_slabs = mcn16_fwd_stream(a.lay).total_frags / MCN16_SLAB; a.bf16 = dtype;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter; a.barf_w = barf_w;
+    a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S; a.out = out;
+    a.act_ws = act_ws; a.slot_bytes = mcn16_slot_bytes(capacity, width); a.enc_ws = enc_ws;
+    a.mask_ws = mask_ws; a.mask_slot_words = mcn16_mask_slot_bytes(capacity, width) / 4;
+    return check("mcnerf_mlp_fwd_16", mcn16_launch_fwd(a, (hipStream_t)stream));
+}
+int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* params, const void* packed_bwd,
+                      const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
+                      const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
+                      int n_rays, int S, const float* out, const float* d_out,
+                      const uint32_t* mask_ws, long long capacity, const void* enc_ws,
+                      void* dy_ws, void* dsh_ws, float* d_rays_o, float* d_rays_d, const uint32_t* gmax_bits, void* stream) {
+    REQ(net_ok(depth, width, skip) && (dtype == 0 || dtype == 1), "mcnerf_mlp_bwd_16");
+    REQ(params && packed_bwd && gmax_bits && rays_o && rays_d && zgrid && barf_w && out && d_out && n_rays >= 0 && S > 0, "mcnerf_mlp_bwd_16");
+    REQ(mask_ws && enc_ws && dy_ws && dsh_ws, "mcnerf_mlp_bwd_16");
+    REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_bwd_16");
+    REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_bwd_16");
+    Mcn16BwdArgs a;
+    a.lay = mcn_make_layout(depth, width, skip);
+    a.params = params; a.packed = packed_bwd; a.stream_slabs = mcn16_bwd_stream(a.lay).total_frags / MCN16_SLAB; a.bf16 = dtype;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter; a.barf_w = barf_w;
+    a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
+    a.out = out; a.d_out = d_out; a.mask_ws = mask_ws; a.mask_slot_words = mcn16_mask_slot_bytes(capacity, width) / 4;
+    a.enc_ws = enc_ws; a.dy_ws = dy_ws; a.slot_bytes = mcn16_slot_bytes(capacity, width); a.dsh_ws = dsh_ws;
+    a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d; a.gmax_bits = gmax_bits;
+    return check("mcnerf_mlp_bwd_16", mcn16_launch_bwd(a, (hipStream_t)stream));
+}
+int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const int32_t* count, int rows,
+                     const void* act_ws, const void* enc_ws, const void* dy_ws, const void* dsh_ws,
+                     long long capacity, float* grads, const uint32_t* gmax_bits, void* stream) {
+    REQ(net_ok(depth, width, skip) && (dtype == 0 || dtype == 1), "mcnerf_mlp_dw_16");
+    REQ(act_ws && enc_ws && dy_ws && dsh_ws && grads && gmax_bits && rows >= 0 && capacity >= rows, "mcnerf_mlp_dw_16");
+    Mcn16DwArgs a;
+    a.lay = mcn_make_layout(depth, width, skip);
+    a.bf16 = dtype; a.count = count; a.rows = rows; a.act_ws = act_ws; a.enc_ws = enc_ws; a.dy_ws = dy_ws; a.dsh_ws = dsh_ws;
+    a.slot_bytes = mcn16_slot_bytes(capacity, width); a.grads = grads; a.gmax_bits = gmax_bits;
+    return check("mcnerf_mlp_dw_16", mcn16_launch_dw(a, (hipStream_t)stream));
 }
 
 int mcnerf_composite_fwd(const float* sig_rgb, const float* rays_d, const float* zgrid, const float* jitter,

@@ -1,0 +1,51 @@
+// Packs the fp32 Linear weights of one net into the two 16-bit fragment STREAMS of the single-pass 16-bit mode
+// (mcnerf_16.h): forward (mlp16_fwd.hip consumes it front to back) and backward (transposed weights in the order of
+// mlp16_bwd.hip).  One thread = one lane's 8 elements of one 1 KiB fragment.  No reference counterpart (torch's addmm
+// reads nn.Linear.weight directly, model/net_block.py:69-74).
+#include "mcnerf_16.h"
+
+template <bool BF>
+__global__ void pack16_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __restrict__ params, char* __restrict__ pf, char* __restrict__ pb) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nf = sf.total_frags * 64, nb = sb.total_frags * 64;
+    if (gid >= nf + nb) return;
+    const bool bwd = gid >= nf;
+    const Mcn16Stream& st = bwd ? sb : sf;
+    const int id = bwd ? gid - nf : gid;
+    const int frag = id >> 6, lane = id & 63;
+    const int i = lane & 31, h = lane >> 5;
+    int s = 0;
+    while (s + 1 < st.nseg && frag >= st.seg[s + 1].first_frag) ++s;
+    const Mcn16Seg sg = st.seg[s];
+    const int loc = frag - sg.first_frag;
+    const int per_tile = sg.a.ksteps + sg.b.ksteps;
+    const int t = loc / per_tile, ks = loc - t * per_tile;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (t < sg.tiles) {                                  // (fragments past the segment's tiles are slab padding: zeros)
+        const bool inb = ks >= sg.a.ksteps;
+        const Mcn16Part p = inb ? sg.b : sg.a;
+        const int kk = inb ? ks - sg.a.ksteps : ks;
+        const int o = 32 * t + i;                        // output index of this lane's row of the fragment tile
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = mcn16_chan(kk, h, j);          // contraction index
+            if (o < p.out_real && c < p.con_real)
+                v[j] = sg.transposed ? params[p.src + (size_t)c * p.ld + p.col0 + o] : params[p.src + (size_t)o * p.ld + p.col0 + c];
+        }
+    }
+    u32x4_t w;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w[d] = Mcn16T<BF>::pack(v[2 * d], v[2 * d + 1]);
+    *reinterpret_cast<u32x4_t*>((bwd ? pb : pf) + (size_t)id * 16) = w;
+}
+
+hipError_t mcn16_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, int bf16, hipStream_t st) {
+    const Mcn16Stream sf = mcn16_fwd_stream(L), sb = mcn16_bwd_stream(L);
+    const int total = (sf.total_frags + sb.total_frags) * 64;
+    const int threads = 256, grid = (total + threads - 1) / threads;
+    if (bf16) hipLaunchKernelGGL(pack16_kernel<true>, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd);
+    else hipLaunchKernelGGL(pack16_kernel<false>, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd);
+    return hipGetLastError();
+}

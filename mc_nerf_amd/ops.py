@@ -99,12 +99,34 @@ def flatten_params(net: Net, tensors, device) -> Tensor:
 
 
 # --------------------------------------------------------------------------- ops
-PRECISIONS = ("f32", "f16x3")
+PRECISIONS = ("f32", "f16x3", "f16", "bf16")
+# single-pass 16-bit MFMA modes (csrc/mcnerf_16.h): name -> dtype code of the C ABI
+DTYPE16 = {"f16": 0, "bf16": 1}
 
 
-def pack_weights(net: Net, params: Tensor, packed: Optional[Tensor] = None, precision: str = "f32") -> Tensor:
-    """Packed weights for the given precision mode (same byte size in both: fp32 fragments or split-f16 fragments)."""
+def is16(precision: str) -> bool:
+    return precision in DTYPE16
+
+
+@dataclass
+class Packed16:
+    """The two 16-bit fragment streams of one net (forward order / transposed backward order)."""
+    fwd: Tensor
+    bwd: Tensor
+
+
+def pack_weights(net: Net, params: Tensor, packed=None, precision: str = "f32"):
+    """Packed weights for the given precision mode: one fp32-sized buffer (f32: fp32 fragments, f16x3: split-f16
+    fragments) or, in the 16-bit modes, a Packed16 pair of fragment streams."""
     assert precision in PRECISIONS
+    if is16(precision):
+        if packed is None:
+            l = _lib.lib()
+            packed = Packed16(torch.empty(int(l.mcnerf_packed_bytes_16(*net.triple, 0)), dtype=torch.uint8, device=params.device),
+                              torch.empty(int(l.mcnerf_packed_bytes_16(*net.triple, 1)), dtype=torch.uint8, device=params.device))
+        _lib.call("mcnerf_pack_weights_16", *net.triple, _p(params), _p(packed.fwd, torch.uint8), _p(packed.bwd, torch.uint8),
+                  DTYPE16[precision], _stream())
+        return packed
     if packed is None:
         packed = torch.empty(packed_count(net), dtype=torch.float32, device=params.device)
     name = "mcnerf_pack_weights" if precision == "f32" else "mcnerf_pack_weights_f16x3"
@@ -130,16 +152,27 @@ def raygen_bwd(pose: Tensor, kinv: Tensor, pix: Tensor, W: int, d_d: Tensor, d_o
 
 @dataclass
 class MlpSave:
-    """Workspaces written by mlp_fwd(save=True) and consumed by mlp_bwd / mlp_dw."""
+    """Workspaces written by mlp_fwd(save=True) and consumed by mlp_bwd / mlp_dw.  In the 16-bit modes `act`, `enc`
+    and `mask` are byte buffers in the fragment-major layouts of csrc/mcnerf_16.h and `sh` is None."""
     capacity: int
     act: Tensor
     enc: Tensor
-    sh: Tensor
+    sh: Optional[Tensor]
     mask: Tensor
 
 
-def alloc_save(net: Net, capacity: int, device) -> MlpSave:
+def ws_bytes_16(net: Net, capacity: int, which: int) -> int:
+    return int(_lib.lib().mcnerf_ws_bytes_16(net.depth, net.width, int(capacity), which))
+
+
+def alloc_save(net: Net, capacity: int, device, precision: str = "f32") -> MlpSave:
     capacity = max(int(capacity), 1)
+    if is16(precision):
+        return MlpSave(capacity,
+                       torch.empty(ws_bytes_16(net, capacity, 0), dtype=torch.uint8, device=device),
+                       torch.empty(ws_bytes_16(net, capacity, 1), dtype=torch.uint8, device=device),
+                       None,
+                       torch.empty(ws_bytes_16(net, capacity, 2) // 4, dtype=torch.int32, device=device))
     return MlpSave(capacity,
                    torch.empty((net.depth + 2) * capacity * net.width, dtype=torch.float32, device=device),
                    torch.empty(capacity * 64, dtype=torch.float32, device=device),
@@ -153,6 +186,12 @@ def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
             precision: str = "f32") -> None:
     n_rays, S = rays_d.shape[0], zgrid.numel()
     assert out.numel() == n_rays * S * 4
+    if is16(precision):
+        _lib.call("mcnerf_mlp_fwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed.fwd, torch.uint8), _p(rays_o), _p(rays_d),
+                  _p(zgrid), _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
+                  _p(out), _p(save.act, torch.uint8) if save else None, save.capacity if save else 0,
+                  _p(save.enc, torch.uint8) if save else None, _p(save.mask, torch.int32) if save else None, _stream())
+        return
     _lib.call("mcnerf_mlp_fwd" if precision == "f32" else "mcnerf_mlp_fwd_f16x3", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
               _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
               _p(out), _p(save.act) if save else None, save.capacity if save else 0,
@@ -166,6 +205,12 @@ def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
             idx: Optional[Tensor] = None, count: Optional[Tensor] = None, max_rows: int = 0,
             precision: str = "f32", gmax: Optional[Tensor] = None) -> None:
     n_rays, S = rays_d.shape[0], zgrid.numel()
+    if is16(precision):
+        _lib.call("mcnerf_mlp_bwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed.bwd, torch.uint8), _p(rays_o), _p(rays_d),
+                  _p(zgrid), _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
+                  _p(out), _p(d_out), _p(save.mask, torch.int32), save.capacity, _p(save.enc, torch.uint8),
+                  _p(dy, torch.uint8), _p(dsh, torch.uint8), _p(d_rays_o), _p(d_rays_d), _p(gmax, torch.int32), _stream())
+        return
     args = [*net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
             _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
             _p(out), _p(d_out), _p(save.mask, torch.int32), save.capacity, _p(save.enc), _p(save.sh),
@@ -178,6 +223,11 @@ def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
 
 def mlp_dw(net: Net, save: MlpSave, dy: Tensor, dsh: Tensor, grads: Tensor, rows: int,
            count: Optional[Tensor] = None, precision: str = "f32", gmax: Optional[Tensor] = None) -> None:
+    if is16(precision):
+        _lib.call("mcnerf_mlp_dw_16", *net.triple, DTYPE16[precision], _p(count, torch.int32), int(rows), _p(save.act, torch.uint8),
+                  _p(save.enc, torch.uint8), _p(dy, torch.uint8), _p(dsh, torch.uint8), save.capacity, _p(grads),
+                  _p(gmax, torch.int32), _stream())
+        return
     args = [*net.triple, _p(count, torch.int32), int(rows), _p(save.act), _p(save.enc), _p(dy), _p(dsh), save.capacity, _p(grads)]
     if precision == "f32":
         _lib.call("mcnerf_mlp_dw", *args, _stream())
@@ -263,6 +313,28 @@ def gather_gt(image_u8: Tensor, pix: Tensor) -> Tensor:
     out = torch.empty(n, 3, dtype=torch.float32, device=pix.device)
     _lib.call("mcnerf_gather_gt", _p(image_u8, torch.uint8), int(image_u8.shape[-1]), _p(pix, torch.int64), n, _p(out), _stream())
     return out
+
+
+def alloc_grad_ws(net: Net, save: MlpSave, precision: str):
+    """dy / dsh workspaces of mlp_bwd for the precision mode."""
+    if is16(precision):
+        return (torch.empty_like(save.act),
+                torch.empty(ws_bytes_16(net, save.capacity, 3), dtype=torch.uint8, device=save.act.device))
+    return torch.empty_like(save.act), torch.empty_like(save.sh)
+
+
+def decode_frags_16(buf: Tensor, n_slots: int, width: int, rows: int, precision: str = "f16") -> Tensor:
+    """Fragment-major 16-bit workspace (csrc/mcnerf_16.h) -> [n_slots, rows, width] fp32.  Debug / test helper."""
+    ks = width // 16
+    dt = torch.float16 if precision == "f16" else torch.bfloat16
+    x = buf.view(dt).view(n_slots, -1, ks, 2, 32, 8)            # [slot][tile][k-step][h][m][j]
+    tiles = x.shape[1]
+    s_, h_, j_ = torch.meshgrid(torch.arange(ks), torch.arange(2), torch.arange(8), indexing="ij")
+    chan = (16 * s_ + 8 * (j_ // 4) + 4 * h_ + (j_ % 4)).reshape(-1).to(buf.device)       # channel of (s, h, j)
+    y = x.permute(0, 1, 4, 2, 3, 5).reshape(n_slots, tiles * 32, ks * 16).float()          # [slot][row][(s,h,j)]
+    out = torch.empty_like(y)
+    out[:, :, chan] = y
+    return out[:, :rows]
 
 
 SPLIT_SCALE_X = 8.0      # MCN_SX of csrc/mcnerf_h.h

@@ -1,5 +1,5 @@
 """Times the fine-net forward / backward chain / weight-gradient calls alone at bench scale (dense rays x 128).
-    python scripts/time_kernels.py [precision] [rays] [width]      (MCNERF_LIB=... selects an ablation build)"""
+    python scripts/time_kernels.py [precision] [rays] [width] [which,...]     (MCNERF_LIB=... selects an ablation build)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,10 +21,10 @@ zg = torch.linspace(1, 8, S, device=dev)
 bw = torch.ones(10, device=dev)
 packed = ops.pack_weights(net, flat, precision=prec)
 out = torch.empty(N, S, 4, device=dev)
-save = ops.alloc_save(net, N * S, dev)
+save = ops.alloc_save(net, N * S, dev, precision=prec)
 d_out = torch.randn(N, S, 4, device=dev, generator=g) * 1e-4
 gmax = d_out.abs().max().reshape(1).view(torch.int32)
-dy, dsh = torch.empty_like(save.act), torch.empty_like(save.sh)
+dy, dsh = ops.alloc_grad_ws(net, save, prec)
 grads = torch.zeros_like(flat)
 d_o, d_d = torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev)
 fns = {
@@ -34,12 +34,17 @@ fns = {
     "dw": lambda: ops.mlp_dw(net, save, dy, dsh, grads, N * S, precision=prec, gmax=gmax),
 }
 res = []
+which = sys.argv[4].split(",") if len(sys.argv) > 4 else list(fns)
+flop = 2.0 * sum(a * b for (a, b) in [sh for sh in net.shapes() if len(sh) == 2]) * N * S
 for name, fn in fns.items():
+    if name not in which:
+        continue
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 4
     e0.record()
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
-    res.append(f"{name} {e0.elapsed_time(e1) / reps:7.2f} ms")
+    ms = e0.elapsed_time(e1) / reps
+    res.append(f"{name} {ms:7.2f} ms ({flop / ms * 1e-9:6.1f} TF)")
 print(os.environ.get("MCNERF_LIB", "default"), prec, f"rows={N * S}", " | ".join(res), "finite", bool(torch.isfinite(out).all()))
