@@ -138,21 +138,21 @@ long long mcnerf_packed_bytes_16(int depth, int width, int skip, int backward);
 int mcnerf_pack_weights_16(int depth, int width, int skip, const float* params, void* packed_fwd, void* packed_bwd,
                            int dtype, void* stream);
 /* which: 0 = activations or pre-activation gradients (all depth+2 slots), 1 = encodings, 2 = ReLU bit masks (all slots),
- *        3 = d(sh.2 outputs / sigma_raw) */
+ *        3 = d(sh.2 outputs / sigma_raw), 4 = sh.2 outputs */
 long long mcnerf_ws_bytes_16(int depth, int width, long long capacity, int which);
-/* mcnerf_mlp_fwd in the 16-bit mode.  act_ws / enc_ws / mask_ws: NULL (all three) for the no-grad path. */
+/* mcnerf_mlp_fwd in the 16-bit mode.  act_ws / enc_ws / mask_ws / sh_ws: NULL (all four) for the no-grad path. */
 int mcnerf_mlp_fwd_16(int depth, int width, int skip, int dtype, const float* params, const void* packed_fwd,
                       const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
                       const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                       int n_rays, int S, float* out,
-                      void* act_ws, long long capacity, void* enc_ws, uint32_t* mask_ws, void* stream);
+                      void* act_ws, long long capacity, void* enc_ws, uint32_t* mask_ws, void* sh_ws, void* stream);
 /* mcnerf_mlp_bwd in the 16-bit mode: dy_ws / dsh_ws receive 16-bit gradients scaled by the power of two derived from
  * *gmax_bits (f16 range); d_rays_o / d_rays_d are accumulated in fp32. */
 int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* params, const void* packed_bwd,
                       const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
                       const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                       int n_rays, int S, const float* out, const float* d_out,
-                      const uint32_t* mask_ws, long long capacity, const void* enc_ws,
+                      const uint32_t* mask_ws, long long capacity, const void* enc_ws, const void* sh_ws,
                       void* dy_ws, void* dsh_ws, float* d_rays_o, float* d_rays_d, const uint32_t* gmax_bits, void* stream);
 /* mcnerf_mlp_dw in the 16-bit mode (fp32 accumulation and fp32 float-atomic output into `grads`). */
 int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const int32_t* count, int rows,

@@ -44,8 +44,8 @@ SIGNATURES = {
     "mcnerf_packed_bytes_16": (_L, [_I, _I, _I, _I]),
     "mcnerf_pack_weights_16": (_I, [_I, _I, _I, _P, _P, _P, _I, _P]),
     "mcnerf_ws_bytes_16": (_L, [_I, _I, _L, _I]),
-    "mcnerf_mlp_fwd_16": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P]),
-    "mcnerf_mlp_bwd_16": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P,
+    "mcnerf_mlp_fwd_16": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
+    "mcnerf_mlp_bwd_16": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,
                                _P, _P, _P, _P, _P, _P]),
     "mcnerf_mlp_dw_16": (_I, [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P]),
     "mcnerf_composite_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),

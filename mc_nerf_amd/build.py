@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmcnerf.so")
-SOURCES = ["api.hip", "pack.hip", "mlp_fwd.hip", "mlp_fwd_h.hip", "mlp_bwd.hip", "mlp_bwd_h.hip", "mlp_dw.hip", "pack16.hip", "mlp16_fwd.hip", "mlp16_stub.hip", "composite.hip", "select_raygen.hip", "optim.hip", "camera.hip"]
+SOURCES = ["api.hip", "pack.hip", "mlp_fwd.hip", "mlp_fwd_h.hip", "mlp_bwd.hip", "mlp_bwd_h.hip", "mlp_dw.hip", "pack16.hip", "mlp16_fwd.hip", "mlp16_bwd.hip", "mlp16_dw.hip", "composite.hip", "select_raygen.hip", "optim.hip", "camera.hip"]
 HEADERS = ["mcnerf_common.h", "mcnerf_kernels.h", "mcnerf_h.h", "mcnerf_16.h", os.path.join("..", "..", "include", "mcnerf.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 

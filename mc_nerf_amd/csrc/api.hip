@@ -203,7 +203,7 @@ long long mcnerf_ws_bytes_16(int depth, int width, long long capacity, int which
         case 0: return (long long)(depth + 2) * (long long)mcn16_slot_bytes(capacity, width);
         case 1: return (long long)mcn16_enc_bytes(capacity);
         case 2: return (long long)(depth + 2) * (long long)mcn16_mask_slot_bytes(capacity, width);
-        case 3: return (long long)mcn16_dsh_bytes(capacity);
+        case 3: case 4: return (long long)mcn16_dsh_bytes(capacity);
     }
     return -1;
 }
@@ -211,13 +211,13 @@ int mcnerf_mlp_fwd_16(int depth, int width, int skip, int dtype, const float* pa
                       const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
                       const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                       int n_rays, int S, float* out,
-                      void* act_ws, long long capacity, void* enc_ws, uint32_t* mask_ws, void* stream) {
+                      void* act_ws, long long capacity, void* enc_ws, uint32_t* mask_ws, void* sh_ws, void* stream) {
     REQ(net_ok(depth, width, skip) && (dtype == 0 || dtype == 1), "mcnerf_mlp_fwd_16");
     REQ(params && packed_fwd && rays_o && rays_d && zgrid && barf_w && out && n_rays >= 0 && S > 0, "mcnerf_mlp_fwd_16");
     REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_fwd_16");
     REQ(!idx || max_rows >= 0, "mcnerf_mlp_fwd_16");
     REQ((long long)n_rays * S < (1ll << 31), "mcnerf_mlp_fwd_16");
-    REQ((act_ws == nullptr) == (enc_ws == nullptr) && (act_ws == nullptr) == (mask_ws == nullptr), "mcnerf_mlp_fwd_16");
+    REQ((act_ws == nullptr) == (enc_ws == nullptr) && (act_ws == nullptr) == (mask_ws == nullptr) && (act_ws == nullptr) == (sh_ws == nullptr), "mcnerf_mlp_fwd_16");
     if (act_ws) REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_fwd_16");
     Mcn16FwdArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
@@ -225,18 +225,18 @@ int mcnerf_mlp_fwd_16(int depth, int width, int skip, int dtype, const float* pa
     a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter; a.barf_w = barf_w;
     a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S; a.out = out;
     a.act_ws = act_ws; a.slot_bytes = mcn16_slot_bytes(capacity, width); a.enc_ws = enc_ws;
-    a.mask_ws = mask_ws; a.mask_slot_words = mcn16_mask_slot_bytes(capacity, width) / 4;
+    a.mask_ws = mask_ws; a.mask_slot_words = mcn16_mask_slot_bytes(capacity, width) / 4; a.sh_ws = sh_ws;
     return check("mcnerf_mlp_fwd_16", mcn16_launch_fwd(a, (hipStream_t)stream));
 }
 int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* params, const void* packed_bwd,
                       const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
                       const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                       int n_rays, int S, const float* out, const float* d_out,
-                      const uint32_t* mask_ws, long long capacity, const void* enc_ws,
+                      const uint32_t* mask_ws, long long capacity, const void* enc_ws, const void* sh_ws,
                       void* dy_ws, void* dsh_ws, float* d_rays_o, float* d_rays_d, const uint32_t* gmax_bits, void* stream) {
     REQ(net_ok(depth, width, skip) && (dtype == 0 || dtype == 1), "mcnerf_mlp_bwd_16");
     REQ(params && packed_bwd && gmax_bits && rays_o && rays_d && zgrid && barf_w && out && d_out && n_rays >= 0 && S > 0, "mcnerf_mlp_bwd_16");
-    REQ(mask_ws && enc_ws && dy_ws && dsh_ws, "mcnerf_mlp_bwd_16");
+    REQ(mask_ws && enc_ws && sh_ws && dy_ws && dsh_ws, "mcnerf_mlp_bwd_16");
     REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_bwd_16");
     REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_bwd_16");
     Mcn16BwdArgs a;
@@ -245,7 +245,7 @@ int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* pa
     a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter; a.barf_w = barf_w;
     a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
     a.out = out; a.d_out = d_out; a.mask_ws = mask_ws; a.mask_slot_words = mcn16_mask_slot_bytes(capacity, width) / 4;
-    a.enc_ws = enc_ws; a.dy_ws = dy_ws; a.slot_bytes = mcn16_slot_bytes(capacity, width); a.dsh_ws = dsh_ws;
+    a.enc_ws = enc_ws; a.sh_ws = sh_ws; a.dy_ws = dy_ws; a.slot_bytes = mcn16_slot_bytes(capacity, width); a.dsh_ws = dsh_ws;
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d; a.gmax_bits = gmax_bits;
     return check("mcnerf_mlp_bwd_16", mcn16_launch_bwd(a, (hipStream_t)stream));
 }

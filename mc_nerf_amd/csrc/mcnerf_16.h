@@ -104,6 +104,7 @@ struct Mcn16FwdArgs {
     void* act_ws; size_t slot_bytes;          // [depth+2] slots of fragment-major activations
     void* enc_ws;                             // fragment-major encodings
     unsigned* mask_ws; size_t mask_slot_words;  // [depth+2] slots of lane-local ReLU bit masks
+    void* sh_ws;                              // fragment-major sh.2 outputs (the SH coefficients; the backward's view-direction term)
 };
 hipError_t mcn16_launch_fwd(const Mcn16FwdArgs& a, hipStream_t st);
 
@@ -118,6 +119,7 @@ struct Mcn16BwdArgs {
     const float* out; const float* d_out;
     const unsigned* mask_ws; size_t mask_slot_words;
     const void* enc_ws;
+    const void* sh_ws;
     void* dy_ws; size_t slot_bytes;           // [depth+2] slots of fragment-major pre-activation gradients (x SG)
     void* dsh_ws;                             // fragment-major d(sh.2 outputs) (columns 0..26) and d sigma_raw (column 27) (x SG)
     float* d_rays_o; float* d_rays_d;
@@ -153,9 +155,14 @@ template <> struct Mcn16T<false> {
     static __device__ __forceinline__ f32x16 mfma(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
-    static __device__ __forceinline__ unsigned pack(float a, float b) { const f16x2_t p = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, p); }
+    // (vector conversion: one v_cvt_pk_f16_f32; two scalar casts become two v_cvt_f16_f32 + v_pack unless something packed follows)
+    static __device__ __forceinline__ unsigned pack(float a, float b) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, f16x2_t));
+    }
     static __device__ __forceinline__ unsigned relu_pack(float a, float b) {
-        f16x2_t p = {(_Float16)a, (_Float16)b};
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f16x2_t p = __builtin_convertvector((f32x2_t){a, b}, f16x2_t);
         p = __builtin_elementwise_max(p, (f16x2_t){(_Float16)0.f, (_Float16)0.f});
         return __builtin_bit_cast(unsigned, p);
     }
@@ -167,7 +174,10 @@ template <> struct Mcn16T<true> {
     static __device__ __forceinline__ f32x16 mfma(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
-    static __device__ __forceinline__ unsigned pack(float a, float b) { const bf16x2_t p = {(__bf16)a, (__bf16)b}; return __builtin_bit_cast(unsigned, p); }
+    static __device__ __forceinline__ unsigned pack(float a, float b) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+    }
     static __device__ __forceinline__ unsigned relu_pack(float a, float b) {
         // relu on the fp32 bit patterns (negative floats are negative integers): no canonicalising v_max, no packed bf16 max needed
         const int ia = __builtin_bit_cast(int, a), ib = __builtin_bit_cast(int, b);

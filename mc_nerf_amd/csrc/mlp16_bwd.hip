@@ -1,0 +1,334 @@
+// Fused NeRF MLP backward (activation-gradient chain), single-pass 16-bit MFMA mode (mcnerf_16.h).  Same structure
+// as mlp16_fwd.hip: a wave carries the gradients of its 32 samples through the transposed network in registers
+// (dX = W^T dY in the "sample on the lane" orientation, so a masked, converted accumulator tile IS the next GEMM's
+// B fragment), the 8 waves share the LDS ring that streams the transposed packed weights in consumption order.
+//   sigmoid / SH backward (lane-local) -> sigma.0^T (kept as a 16-bit partial) -> sh.2^T -> sh.0^T (+ partial) ->
+//   trunk D-1 .. 1 (the skip layer's and layer 0's encoded columns accumulate the encoded-input gradient) ->
+//   encoding backward -> per-ray d o / d d (segmented wave reduction + fp32 atomics).
+// Every pre-activation gradient is written fragment-major to dy_ws / dsh_ws (operands of mlp16_dw.hip), scaled by the
+// per-launch power of two SG (f16 range; derived from max|d_out| as in the split-f16 mode).
+// Replaces autograd through model/net_block.py:22-33, 67-78 and model/mc_nerf.py:602, 635, 690-691.
+#include "mcnerf_16.h"
+
+template <int W>
+struct Bwd16Smem {
+    static constexpr int oW2 = MCN16_RING * MCN16_SLAB * 1024;     // sigma.2 weight row [W] fp32
+    static constexpr int oBarf = oW2 + W * 4;                      // BARF weights [10] (+ pad)
+    static constexpr int total = oBarf + 16 * 4;
+};
+
+// GEMM over one segment of NTILES output tiles x KSTEPS contraction steps (B fragments `in`), software-pipelined like
+// the forward (A fragments MCN16_PF steps ahead, epilogue of tile t between the MFMAs of tile t + 1).
+//   MODE 0: out[2t], out[2t+1] = pack(acc)                      (a partial sum kept in 16 bit)
+//   MODE 1: out = mask(pack(acc)), saved                         (masked by the forward's ReLU bits `mk`)
+//   MODE 2: as 1, with the accumulator started at the partial sum already in out[2t], out[2t+1]
+//   MODE 3: NTILES == 2: acc2[t] += ...                          (fp32 accumulators owned by the caller, no epilogue)
+template <int W, bool BF, int KSTEPS, int NTILES, int MODE, int NOUT = W / 16>
+__device__ __forceinline__ void mcn16_bwd_seg(Mcn16Ring& ring, char* smem, int lane, const u32x4_t (&in)[W / 16], u32x4_t (&out)[NOUT],
+                                              const unsigned (&mk)[W >= 64 ? W / 64 : 1], f32x16 (&acc2)[2], char* save_lane) {
+    using T = Mcn16T<BF>;
+    constexpr int F = NTILES * KSTEPS;
+    constexpr bool EPI = MODE != 3;
+    constexpr int NSL = EPI ? (MODE == 0 ? 8 : 10) : 0;
+    constexpr int START = (KSTEPS >= NSL + 3) ? 2 : 0;
+    constexpr int SPS = EPI ? (NSL + KSTEPS - START - 1) / (KSTEPS - START) : 1;
+    constexpr int LAST = EPI ? START + (NSL + SPS - 1) / SPS - 1 : 0;
+    constexpr int INIT_AT = (KSTEPS - 4) > LAST ? (KSTEPS - 4) : LAST;
+    Mcn16Cursor cur;
+    u32x4_t af[MCN16_PF];
+    f32x16 acc[2];
+    u32x4_t o0, o1;
+    auto acc_init = [&](f32x16& a, int t) {
+        if (MODE == 2) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                a[2 * d] = T::lo(out[2 * t][d]); a[2 * d + 1] = T::hi(out[2 * t][d]);
+                a[8 + 2 * d] = T::lo(out[2 * t + 1][d]); a[8 + 2 * d + 1] = T::hi(out[2 * t + 1][d]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[e] = 0.f;
+        }
+    };
+    auto epi_slice = [&](const f32x16& a, int t, int i) {
+        if (i < 8) {
+            unsigned w = T::pack(a[2 * i], a[2 * i + 1]);
+            if (MODE != 0) w = mcn16_pkmul(w, (mk[t >> 1] >> (8 * (t & 1) + 7 - i)) & 0x00010001u);
+            if (i < 4) o0[i] = w; else o1[i - 4] = w;
+            if (i == 7) { out[2 * t] = o0; out[2 * t + 1] = o1; }
+        } else if (MODE != 0) {
+            if (i == 8) __builtin_nontemporal_store(o0, reinterpret_cast<u32x4_t*>(save_lane + (2 * t) * 1024));
+            else __builtin_nontemporal_store(o1, reinterpret_cast<u32x4_t*>(save_lane + (2 * t + 1) * 1024));
+        }
+    };
+    cur.cur = ring.next_off;
+#pragma unroll
+    for (int i = 0; i < MCN16_PF; ++i)
+        if (i < F) af[i] = *reinterpret_cast<const u32x4_t*>(smem + ring.next_off + i * 1024 + lane * 16);
+    if (EPI) acc_init(acc[0], 0);
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int f = t * KSTEPS + s;
+            mcn16_before_mfma<F>(ring, smem, cur, f);
+            const u32x4_t a_now = af[f % MCN16_PF];
+            if (f + MCN16_PF < F)
+                af[f % MCN16_PF] = *reinterpret_cast<const u32x4_t*>(smem + mcn16_frag_off(ring, cur, f, f + MCN16_PF) + lane * 16);
+            if (EPI && t > 0 && s >= START) {
+#pragma unroll
+                for (int i = (s - START) * SPS; i < (s - START + 1) * SPS; ++i)
+                    if (i < NSL) epi_slice(acc[(t - 1) & 1], t - 1, i);
+            }
+            if (EPI && s == INIT_AT && t + 1 < NTILES) acc_init(acc[(t + 1) & 1], t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (EPI) acc[t & 1] = T::mfma(a_now, in[s], acc[t & 1]);
+            else acc2[t & 1] = T::mfma(a_now, in[s], acc2[t & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (EPI) {
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) epi_slice(acc[(NTILES - 1) & 1], NTILES - 1, i);
+    }
+}
+
+template <int W, bool BF>
+__global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16BwdArgs a) {
+    using T = Mcn16T<BF>;
+    using SM = Bwd16Smem<W>;
+    constexpr int NT = W / 32, KS = W / 16, MW = W >= 64 ? W / 64 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int D = a.lay.depth, skip = a.lay.skip;
+    const long long total = a.count ? (long long)min(*a.count, a.max_rows) : (long long)a.n_rays * a.S;
+    if ((long long)blockIdx.x * MCN16_ROWS >= total) return;
+
+    float* sw2 = reinterpret_cast<float*>(smem + SM::oW2);
+    for (int i = tid; i < W; i += 64 * MCN16_WAVES) sw2[i] = a.params[a.lay.pWs2 + i];
+    float* sbarf = reinterpret_cast<float*>(smem + SM::oBarf);
+    if (tid < MCN_NFREQ) sbarf[tid] = a.barf_w[tid];
+    // gradient scale: a power of two that puts max|d_out| of the launch near 2^4 (4096x headroom below the f16 maximum
+    // for growth through the layers); bf16 has fp32's range but shares the arithmetic
+    const float gmax = __uint_as_float(*a.gmax_bits);
+    const float sg = (gmax > 0.f && gmax < 3e38f) ? exp2f(4.f - ceilf(log2f(gmax))) : 1.f;
+    const float inv_sg = 1.0f / sg;
+    __syncthreads();
+
+    Mcn16Ring ring;
+    mcn16_ring_start(ring, smem, a.packed, a.stream_slabs, wave, lane);
+    const float* w2_h = sw2 + 4 * h;
+
+    for (long long pass = blockIdx.x; pass * MCN16_ROWS < total; pass += gridDim.x) {
+        const long long tile = pass * MCN16_WAVES + wave;
+        const long long g = tile * 32 + m;
+        const bool valid = g < total;
+        const long long gc = valid ? g : total - 1;
+        const unsigned* mask_lane = a.mask_ws + ((size_t)tile * 64 + lane) * MW;
+        char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)tile * KS * 1024 + lane * 16;
+        auto load_mask = [&](unsigned (&mk)[MW], int slot) {
+#pragma unroll
+            for (int i = 0; i < MW; ++i) mk[i] = mask_lane[(size_t)slot * a.mask_slot_words + i];
+        };
+        // ---- per-sample prologue (lane-local): sigmoid and SH backward
+        int ray, j;
+        if (a.idx) { const int2 rj = a.idx[gc]; ray = rj.x; j = rj.y; }
+        else { ray = (int)(gc / a.S); j = (int)(gc - (long long)ray * a.S); }
+        unsigned mk_s[MW], mk_c[MW], mk_t[MW];
+        load_mask(mk_s, D); load_mask(mk_c, D + 1); load_mask(mk_t, D - 1);
+        float zv = a.zgrid[j];
+        if (a.jitter) zv = __fadd_rn(zv, a.jitter[ray]);
+        const size_t addr = (size_t)ray * a.S + j;
+        const f32x4 o = *reinterpret_cast<const f32x4*>(a.out + addr * 4);
+        f32x4 go = *reinterpret_cast<const f32x4*>(a.d_out + addr * 4);
+        if (!valid) go = f32x4{0.f, 0.f, 0.f, 0.f};          // rows past the count contribute exactly zero everywhere
+        const float x = a.rays_d[ray * 3], y = a.rays_d[ray * 3 + 1], z = a.rays_d[ray * 3 + 2];
+        float p[3];
+        p[0] = __fadd_rn(a.rays_o[ray * 3 + 0], __fmul_rn(x, zv));
+        p[1] = __fadd_rn(a.rays_o[ray * 3 + 1], __fmul_rn(y, zv));
+        p[2] = __fadd_rn(a.rays_o[ray * 3 + 2], __fmul_rn(z, zv));
+        float bas[9];
+        mcn_sh_basis(x, y, z, bas);
+        float dpre[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dpre[c] = go[1 + c] * o[1 + c] * (1.f - o[1 + c]) * sg;
+        const float dsg = go[0] * sg;
+        // dsh fragments (2 k-steps over the 32 padded sh.2 outputs): element (s, j) = column n = c(s,h,j); column 27 carries
+        // d sigma for the sigma.2 weight gradient (the packed sh.2^T has zero rows there)
+        u32x4_t dshf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int n0 = mcn16_chan(s, 0, 2 * d + u), n1 = n0 + 4;
+                    const float v0 = n0 < MCN_NSH ? dpre[n0 / 9] * bas[n0 % 9] : (n0 == MCN_NSH ? dsg : 0.f);
+                    const float v1 = n1 < MCN_NSH ? dpre[n1 / 9] * bas[n1 % 9] : (n1 == MCN_NSH ? dsg : 0.f);
+                    v[u] = h ? v1 : v0;
+                }
+                dshf[s][d] = T::pack(v[0], v[1]);
+            }
+        {
+            char* e = reinterpret_cast<char*>(a.dsh_ws) + (size_t)tile * 2 * 1024 + lane * 16;
+            __builtin_nontemporal_store(dshf[0], reinterpret_cast<u32x4_t*>(e));
+            __builtin_nontemporal_store(dshf[1], reinterpret_cast<u32x4_t*>(e + 1024));
+        }
+
+        u32x4_t xa[KS], xb[KS];
+        f32x16 denc[2];
+        u32x4_t dencp[4];            // the skip layer's share of the encoded-input gradient, parked in 16 bit until layer 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dencp[i] = u32x4_t{0u, 0u, 0u, 0u};
+        // ---- dY of sigma.0 = d sigma * w_sigma2, masked by the sigma hidden layer's ReLU bits (outer product, no GEMM)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(w2_h + 16 * s), wb = *reinterpret_cast<const f32x4*>(w2_h + 16 * s + 8);
+            const int t = s >> 1;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float v0 = (d < 2 ? wa[2 * d] : wb[2 * d - 4]) * dsg, v1 = (d < 2 ? wa[2 * d + 1] : wb[2 * d - 3]) * dsg;
+                const int i = 4 * (s & 1) + d;
+                xa[s][d] = mcn16_pkmul(T::pack(v0, v1), (mk_s[t >> 1] >> (8 * (t & 1) + 7 - i)) & 0x00010001u);
+            }
+            __builtin_nontemporal_store(xa[s], reinterpret_cast<u32x4_t*>(dy_lane + (size_t)D * a.slot_bytes + s * 1024));
+        }
+        // ---- sigma.0^T (partial, 16 bit) ; sh.2^T -> dY of sh.0 ; sh.0^T + partial -> dY_{D-1}
+        mcn16_bwd_seg<W, BF, KS, NT, 0>(ring, smem, lane, xa, xb, mk_s, denc, nullptr);
+        {
+            u32x4_t dsh_in[KS];
+            dsh_in[0] = dshf[0]; dsh_in[1] = dshf[1];
+            mcn16_bwd_seg<W, BF, 2, NT, 1>(ring, smem, lane, dsh_in, xa, mk_c, denc, dy_lane + (size_t)(D + 1) * a.slot_bytes);
+        }
+        unsigned mk_n[MW];                                     // masks are fetched one layer ahead of their use
+        if (D >= 2) load_mask(mk_n, D - 2);
+        mcn16_bwd_seg<W, BF, KS, NT, 2>(ring, smem, lane, xa, xb, mk_t, denc, dy_lane + (size_t)(D - 1) * a.slot_bytes);
+        // ---- trunk, last layer to first: xb = dY_l
+        for (int l = D - 1; l >= 1; --l) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) xa[s] = xb[s];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) mk_t[i] = mk_n[i];
+            if (l >= 2) load_mask(mk_n, l - 2);
+            if (l == skip) mcn16_bwd_seg<W, BF, KS, 2, 0, 4>(ring, smem, lane, xa, dencp, mk_t, denc, nullptr);
+            mcn16_bwd_seg<W, BF, KS, NT, 1>(ring, smem, lane, xa, xb, mk_t, denc, dy_lane + (size_t)(l - 1) * a.slot_bytes);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                denc[t][2 * d] = T::lo(dencp[2 * t][d]); denc[t][2 * d + 1] = T::hi(dencp[2 * t][d]);
+                denc[t][8 + 2 * d] = T::lo(dencp[2 * t + 1][d]); denc[t][8 + 2 * d + 1] = T::hi(dencp[2 * t + 1][d]);
+            }
+        mcn16_bwd_seg<W, BF, KS, 2, 3>(ring, smem, lane, xb, xa, mk_t, denc, nullptr);       // layer 0: encoded columns
+
+        // ---- encoding backward -> d position; SH view-direction term; per-ray reduction
+        if (a.d_rays_o || a.d_rays_d) {
+            // this lane holds d enc of channels 32 te + 8 q + 4 h + e (register 4 q + e of denc[te]); channel 3 + 20 a + f is
+            // w_f sin(2^f x_a), + 10: w_f cos(2^f x_a)  ->  d x_a += 2^f w_f (cos dsin - sin dcos)
+            auto dch = [&](int ch) -> float {              // d enc of channel ch if this lane half holds it, else 0
+                const int hh = (ch >> 2) & 1;
+                const float v = denc[ch >> 5][4 * ((ch >> 3) & 3) + (ch & 3)];
+                return (h == hh) ? v : 0.f;
+            };
+            float dpos[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                float s, c;
+                mcn_sincos(p[ax], s, c);
+                float acc = dch(ax);
+#pragma unroll
+                for (int f = 0; f < MCN_NFREQ; ++f) {
+                    const float k = (float)(1 << f) * sbarf[f];
+                    acc = fmaf(k * c, dch(3 + 20 * ax + f), acc);
+                    acc = fmaf(-k * s, dch(3 + 20 * ax + 10 + f), acc);
+                    const float s2 = 2.f * s * c, c2 = (c - s) * (c + s);
+                    s = s2; c = c2;
+                }
+                dpos[ax] = acc;
+            }
+            // SH term: d pre_c / d dir = sum_i sh[9c + i] d basis_i / d dir with the forward's saved sh.2 outputs (model/net_utils.py:154-169)
+            float ddir[3] = {0.f, 0.f, 0.f};
+            {
+                const u32x4_t s0 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 2 * 1024 + lane * 16);
+                const u32x4_t s1 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 2 * 1024 + 1024 + lane * 16);
+                const float C1 = 0.4886025119029199f, C20 = 1.0925484305920792f, C22 = 0.31539156525252005f, C24 = 0.5462742152960396f;
+                // derivative of basis i wrt (x, y, z)
+                const float gx[9] = {0.f, 0.f, 0.f, -C1, C20 * y, 0.f, -2.f * C22 * x, -C20 * z, 2.f * C24 * x};
+                const float gy[9] = {0.f, -C1, 0.f, 0.f, C20 * x, -C20 * z, -2.f * C22 * y, 0.f, -2.f * C24 * y};
+                const float gz[9] = {0.f, 0.f, C1, 0.f, 0.f, -C20 * y, 4.f * C22 * z, -C20 * x, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const unsigned w = s ? s1[jj >> 1] : s0[jj >> 1];
+                        const float v = (jj & 1) ? T::hi(w) : T::lo(w);
+                        const int n0 = mcn16_chan(s, 0, jj), n1 = n0 + 4;
+                        const float kx = h ? (n1 < MCN_NSH ? dpre[n1 / 9] * gx[n1 % 9] : 0.f) : (n0 < MCN_NSH ? dpre[n0 / 9] * gx[n0 % 9] : 0.f);
+                        const float ky = h ? (n1 < MCN_NSH ? dpre[n1 / 9] * gy[n1 % 9] : 0.f) : (n0 < MCN_NSH ? dpre[n0 / 9] * gy[n0 % 9] : 0.f);
+                        const float kz = h ? (n1 < MCN_NSH ? dpre[n1 / 9] * gz[n1 % 9] : 0.f) : (n0 < MCN_NSH ? dpre[n0 / 9] * gz[n0 % 9] : 0.f);
+                        ddir[0] = fmaf(kx, v, ddir[0]); ddir[1] = fmaf(ky, v, ddir[1]); ddir[2] = fmaf(kz, v, ddir[2]);
+                    }
+            }
+            float red[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float dp = dpos[c] + __shfl_xor(dpos[c], 32);
+                const float dd = ddir[c] + __shfl_xor(ddir[c], 32);
+                red[c] = dp * inv_sg;                              // d origin
+                red[3 + c] = (dp * zv + dd) * inv_sg;              // d direction: through x = o + d z, plus the SH term
+            }
+            // segmented inclusive scan over the 32 samples (rows of one ray are contiguous): the last row of each run adds
+            // the run's sum with 6 atomics instead of 6 per sample
+            const int rkey = valid ? ray : -1;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const int rk = __shfl_up(rkey, off, 32);
+                const bool take = (m >= off) && rk == rkey;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const float up = __shfl_up(red[c], off, 32);
+                    red[c] += take ? up : 0.f;
+                }
+            }
+            const int rnext = __shfl_down(rkey, 1, 32);
+            if (h == 0 && valid && (m == 31 || rnext != rkey)) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (a.d_rays_o) atomicAdd(a.d_rays_o + ray * 3 + c, red[c]);
+                    if (a.d_rays_d) atomicAdd(a.d_rays_d + ray * 3 + c, red[3 + c]);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int W>
+static hipError_t launch_bwd16(const Mcn16BwdArgs& a, long long max_rows, hipStream_t st) {
+    using SM = Bwd16Smem<W>;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    long long passes = (max_rows + MCN16_ROWS - 1) / MCN16_ROWS;
+    if (passes <= 0) return hipSuccess;
+    const int grid = (int)(passes < cus ? passes : cus);
+    void (*kern)(Mcn16BwdArgs) = a.bf16 ? mlp16_bwd_kernel<W, true> : mlp16_bwd_kernel<W, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * MCN16_WAVES), SM::total, st, a);
+    return hipGetLastError();
+}
+
+hipError_t mcn16_launch_bwd(const Mcn16BwdArgs& a, hipStream_t st) {
+    const long long max_rows = a.count ? (long long)a.max_rows : (long long)a.n_rays * a.S;
+    switch (a.lay.width) {
+        case 256: return launch_bwd16<256>(a, max_rows, st);
+        case 128: return launch_bwd16<128>(a, max_rows, st);
+        case 64:  return launch_bwd16<64>(a, max_rows, st);
+        case 32:  return launch_bwd16<32>(a, max_rows, st);
+    }
+    return hipErrorInvalidValue;
+}

@@ -1,0 +1,261 @@
+// Weight / bias gradients of the NeRF MLPs, single-pass 16-bit MFMA mode (mcnerf_16.h):
+//     dW[n][k] = sum_m dY[m][n] X[m][k],   db[n] = sum_m dY[m][n]
+// over the fragment-major 16-bit workspaces written by mlp16_fwd.hip (X) and mlp16_bwd.hip (dY, scaled by SG).
+// Replaces the dW half of autograd's addmm backward for every nn.Linear of CorseFine_NeRF (model/net_block.py:51-65).
+//
+// HBM-bound streaming kernel: persistent, one workgroup (8 waves) per CU takes a contiguous run of 32-row tiles, keeps
+// its whole dW block in MFMA accumulators and adds it with one fp32 float-atomic pass at the end.  A 32-row tile of both
+// operands ((N + K) / 16 fragments of 1 KiB) is one stage of a 4-stage LDS ring filled by LDS-DMA (inline asm, counted
+// vmcnt, one raw barrier per tile).  The contraction runs over SAMPLES, which sit on the lanes of the saved fragments,
+// so both MFMA operands are read with ds_read_b64_tr_b16 (the transposing LDS read): a fragment's 16-byte chunks are
+// (lane half hh, sample m) -> 8 channels, and a 4-sample x 16-channel block of a transposed read touches the chunks
+// (s, hh, m .. m+3) of two fragments s.  The DMA places chunk (hh, m) of fragment s at position
+// 32 hh + (m ^ 4 (2 (s & 1) + hh)), which spreads the 16 chunks of one 32-lane half over all 64 banks.
+#include "mcnerf_16.h"
+
+struct Dw16Seg {
+    const char* dY; int ksn;      // fragment-major [tile][ksn][64][8]: N = 16 ksn columns
+    const char* X;  int ksk;      // fragment-major [tile][ksk][64][8]: K = 16 ksk columns
+    int n_lo, n_real, k_real;     // outputs n_lo <= n < n_real are real (row n - n_lo of dW); inputs k < k_real
+    float* dW; int ldw;
+    float* db;
+};
+
+constexpr int dw16_pick(int N, int K, bool want_vn) {
+    int bestG = 0, bestVN = 1, bestKT = 1;
+    for (int vn = 4; vn >= 1; vn /= 2)
+        for (int kt = 4; kt >= 1; kt /= 2) {
+            if (32 * vn > N || 32 * kt > K) continue;
+            const int g = (N / (32 * vn)) * (K / (32 * kt));
+            if (g > MCN16_WAVES) continue;
+            const bool better = g > bestG || (g == bestG && vn * kt > bestVN * bestKT) || (g == bestG && vn * kt == bestVN * bestKT && vn > bestVN);
+            if (better) { bestG = g; bestVN = vn; bestKT = kt; }
+        }
+    return want_vn ? bestVN : bestKT;
+}
+
+#define DW16_STAGES 4
+
+template <int N, int K, bool BF>
+__global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_kernel(Dw16Seg sg, const int* count, int rows_cap, const unsigned* gmax_bits) {
+    using T = Mcn16T<BF>;
+    constexpr int KSN = N / 16, KSK = K / 16, P = KSN + KSK;          // 1 KiB pieces per tile
+    constexpr int PW = (P + MCN16_WAVES - 1) / MCN16_WAVES;           // pieces per wave (the trailing waves may issue PW - 1)
+    constexpr int VN = dw16_pick(N, K, true), KT = dw16_pick(N, K, false);
+    constexpr int NG = N / (32 * VN), KG = K / (32 * KT), G = NG * KG, MS = MCN16_WAVES / G;
+    static_assert(G >= 1 && MCN16_WAVES % G == 0, "wave tiling");
+    constexpr int STAGE = P * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
+
+    const int rows = count ? min(*count, rows_cap) : rows_cap;
+    const int ntiles = (rows + 31) / 32;
+    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t0 = blockIdx.x * per;
+    if (t0 >= ntiles) return;
+    const int t1 = min(t0 + per, ntiles);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gi = wave % G, ms = wave / G;
+    const int nbase = (gi % NG) * 32 * VN, kbase = (gi / NG) * 32 * KT;
+    const float gmax = gmax_bits ? __uint_as_float(*gmax_bits) : 1.f;
+    const float sgs = (gmax > 0.f && gmax < 3e38f) ? exp2f(4.f - ceilf(log2f(gmax))) : 1.f;
+
+    // ---- LDS-DMA pieces of this wave: piece pi = wave + 8 i (dY fragments first, then X fragments)
+    const unsigned lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem);
+    const char* src[PW];
+    const int hh = lane >> 5, mm = lane & 31;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int pi = wave + MCN16_WAVES * i;
+        const bool isY = pi < KSN;
+        const int s = isY ? pi : pi - KSN;
+        const int m_src = mm ^ (4 * (2 * (s & 1) + hh));
+        const char* base = isY ? sg.dY + ((size_t)t0 * KSN + s) * 1024 : sg.X + ((size_t)t0 * KSK + s) * 1024;
+        src[i] = base + (hh * 32 + m_src) * 16;
+    }
+    const int np = (P % MCN16_WAVES == 0 || wave < P % MCN16_WAVES) ? PW : PW - 1;      // wave-uniform
+    auto fill = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int pi = wave + MCN16_WAVES * i;
+            if (i < np) mcn16_dma16(src[i], lds_base + stage * STAGE + pi * 1024);
+            src[i] += (size_t)(pi < KSN ? KSN : KSK) * 1024;
+        }
+    };
+#define DW16_WAIT_ASM(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
+#define DW16_WAIT(k) do { if (np == PW) DW16_WAIT_ASM((k) * PW); else DW16_WAIT_ASM((k) * (PW - 1)); } while (0)
+
+    f32x16 acc[VN][KT];
+    mcn_zero<VN, KT>(acc);
+    float bsum[VN];
+#pragma unroll
+    for (int t = 0; t < VN; ++t) bsum[t] = 0.f;
+    const bool bias = sg.db && kbase == 0;                            // wave-uniform
+
+    // ---- per-lane LDS offsets of the transposed reads.  A fragment (n-tile tn, m-step u, half v): 16-lane group G16 = lane >> 4,
+    //      group lane gl = 4 q + p: row m = 16 u + 8 (G16 >> 1) + 4 v + q, columns n0 + 4 p .. + 3 with n0 = 32 tn + 16 (G16 & 1):
+    //      fragment s = 2 tn + (G16 & 1), chunk (hh' = p & 1, m), byte 8 (p >> 1) inside the chunk.
+    const int g16 = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int hp = p & 1;
+    const int cxor = 4 * (2 * (g16 & 1) + hp);                        // (s & 1) = (G16 & 1) for every tile
+    int roff[2][2];                                                   // [u][v]: offset inside one fragment's 1 KiB piece
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int m = 16 * u + 8 * (g16 >> 1) + 4 * v + q;
+            roff[u][v] = (hp * 32 + (m ^ cxor)) * 16 + 8 * (p >> 1);
+        }
+    const int fragA0 = (nbase / 16) + (g16 & 1);                      // first dY fragment of this lane (n-tile 0 of the wave tile)
+    const int fragB0 = KSN + (kbase / 16) + (g16 & 1);
+
+    int nt = t1 - t0;
+    fill(0);
+    if (nt > 1) fill(1);
+    if (nt > 2) fill(2);
+    if (nt > 2) DW16_WAIT(2); else if (nt > 1) DW16_WAIT(1); else DW16_WAIT(0);
+    int cur = 0;
+    for (int it = 0; it < nt; ++it) {
+        if (it + 3 < nt) fill((cur + 3) & (DW16_STAGES - 1));
+        if ((it % MS) == ms) {                                        // wave-uniform: waves sharing an output tile alternate tiles
+            const char* st = smem + cur * STAGE;
+            u32x4_t af[2][VN], bf[2][KT];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int t = 0; t < VN; ++t) {
+                    const char* fp = st + (fragA0 + 2 * t) * 1024;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(fp + roff[u][0]));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(fp + roff[u][1]));
+                    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+                    af[u][t] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+                }
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const char* fp = st + (fragB0 + 2 * t) * 1024;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(fp + roff[u][0]));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(fp + roff[u][1]));
+                    const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+                    bf[u][t] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < VN; ++t) {
+                    if (bias) {          // column sums of dY: the 8 samples of this lane's column
+                        if (BF) {
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) bsum[t] += T::lo(af[u][t][d]) + T::hi(af[u][t][d]);
+                        } else {
+                            // (whole-vector bit cast, then pairs: hipcc 7.2 miscompiles bit_cast<f16x2>(u32x4[d]) feeding fdot2 -- it
+                            //  reads element 0 four times)
+                            const f16x2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+                            const f16x8_t hv = __builtin_bit_cast(f16x8_t, af[u][t]);
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) bsum[t] = __builtin_amdgcn_fdot2(f16x2_t{hv[2 * d], hv[2 * d + 1]}, ones, bsum[t], false);
+                        }
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) acc[t][kt] = T::mfma(af[u][t], bf[u][kt], acc[t][kt]);
+                }
+        }
+        const int left = nt - 1 - it;
+        if (left >= 3) DW16_WAIT(2); else if (left == 2) DW16_WAIT(1); else DW16_WAIT(0);
+        cur = (cur + 1) & (DW16_STAGES - 1);
+    }
+#undef DW16_WAIT
+#undef DW16_WAIT_ASM
+    // ---- accumulators -> global (float atomics; one register = two 128-byte row segments)
+    const int r = lane & 31, h = lane >> 5;
+    const float inv = 1.0f / sgs;
+#pragma unroll
+    for (int t = 0; t < VN; ++t)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int k = kbase + 32 * kt + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n >= sg.n_lo && n < sg.n_real && k < sg.k_real) atomicAdd(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + k, acc[t][kt][e] * inv);
+            }
+        }
+    if (bias) {
+#pragma unroll
+        for (int t = 0; t < VN; ++t) {
+            const float b = (bsum[t] + __shfl_xor(bsum[t], 32)) * inv;
+            const int n = nbase + 32 * t + r;
+            if (h == 0 && n >= sg.n_lo && n < sg.n_real) atomicAdd(sg.db + (n - sg.n_lo), b);
+        }
+    }
+}
+
+static int dw16_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <int N, int K>
+static hipError_t dw16_launch_t(const Dw16Seg& s, const int* count, int rows_cap, int bf16, const unsigned* gmax_bits, hipStream_t st) {
+    const int ntiles = (rows_cap + 31) / 32;
+    int grid = dw16_num_cus();
+    if (grid > ntiles) grid = ntiles;
+    const size_t lds = (size_t)DW16_STAGES * (N + K) / 16 * 1024;
+    void (*kern)(Dw16Seg, const int*, int, const unsigned*) = bf16 ? dw16_kernel<N, K, true> : dw16_kernel<N, K, false>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * MCN16_WAVES), lds, st, s, count, rows_cap, gmax_bits);
+    return hipGetLastError();
+}
+
+static hipError_t dw16_launch(const Dw16Seg& s, const int* count, int rows_cap, int bf16, const unsigned* gmax_bits, hipStream_t st) {
+    if (rows_cap <= 0) return hipSuccess;
+#define DW16_CASE(NN, KK) case NN * 1000 + KK: return dw16_launch_t<NN, KK>(s, count, rows_cap, bf16, gmax_bits, st)
+    switch (s.ksn * 16 * 1000 + s.ksk * 16) {
+        DW16_CASE(256, 256); DW16_CASE(256, 64); DW16_CASE(32, 256);
+        DW16_CASE(128, 128); DW16_CASE(128, 64); DW16_CASE(32, 128);
+        DW16_CASE(64, 64); DW16_CASE(32, 64); DW16_CASE(32, 32);
+        default: return hipErrorInvalidValue;
+    }
+#undef DW16_CASE
+}
+
+hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
+    const McnLayout& L = a.lay;
+    const int W = L.width, D = L.depth, KS = W / 16;
+    auto act = [&](int slot) { return reinterpret_cast<const char*>(a.act_ws) + (size_t)slot * a.slot_bytes; };
+    auto dy = [&](int slot) { return reinterpret_cast<const char*>(a.dy_ws) + (size_t)slot * a.slot_bytes; };
+    const char* enc = reinterpret_cast<const char*>(a.enc_ws);
+    const char* dsh = reinterpret_cast<const char*>(a.dsh_ws);
+    hipError_t e;
+    for (int l = 0; l < D; ++l) {
+        const int ldw = mcn_in_features(D, W, L.skip, l);
+        if (l == 0 || l == L.skip) {      // encoded-input columns
+            Dw16Seg s = {dy(l), KS, enc, MCN16_ENCKS, 0, W, MCN_ENC, a.grads + L.pW[l], ldw, a.grads + L.pB[l]};
+            if ((e = dw16_launch(s, a.count, a.rows, a.bf16, a.gmax_bits, st)) != hipSuccess) return e;
+        }
+        if (l > 0) {                      // hidden-input columns (after the 63 encoded ones at the skip layer)
+            Dw16Seg s = {dy(l), KS, act(l - 1), KS, 0, W, W, a.grads + L.pW[l] + (l == L.skip ? MCN_ENC : 0), ldw,
+                         l == L.skip ? nullptr : a.grads + L.pB[l]};
+            if ((e = dw16_launch(s, a.count, a.rows, a.bf16, a.gmax_bits, st)) != hipSuccess) return e;
+        }
+    }
+    Dw16Seg s1 = {dy(D), KS, act(D - 1), KS, 0, W, W, a.grads + L.pWs1, W, a.grads + L.pBs1};
+    if ((e = dw16_launch(s1, a.count, a.rows, a.bf16, a.gmax_bits, st)) != hipSuccess) return e;
+    Dw16Seg c1 = {dy(D + 1), KS, act(D - 1), KS, 0, W, W, a.grads + L.pWc1, W, a.grads + L.pBc1};
+    if ((e = dw16_launch(c1, a.count, a.rows, a.bf16, a.gmax_bits, st)) != hipSuccess) return e;
+    Dw16Seg c2 = {dsh, 2, act(D + 1), KS, 0, MCN_NSH, W, a.grads + L.pWc2, W, a.grads + L.pBc2};
+    if ((e = dw16_launch(c2, a.count, a.rows, a.bf16, a.gmax_bits, st)) != hipSuccess) return e;
+    // sigma.2 (1 x W): d sigma sits in column 27 of dsh, its input is the sigma hidden layer
+    Dw16Seg s2 = {dsh, 2, act(D), KS, MCN_NSH, MCN_NSH + 1, W, a.grads + L.pWs2, W, a.grads + L.pBs2};
+    return dw16_launch(s2, a.count, a.rows, a.bf16, a.gmax_bits, st);
+}

@@ -246,6 +246,14 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
                 acc = T::mfma(af, xa[s], acc);
             }
         }
+        if (SAVE) {          // the SH coefficients (bias included) for the backward's view-direction term: 2 fragments of 16 bit
+            char* e = reinterpret_cast<char*>(a.sh_ws) + (size_t)tile * 2 * 1024 + lane * 16;
+            u32x4_t s0, s1;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { s0[d] = T::pack(acc[2 * d], acc[2 * d + 1]); s1[d] = T::pack(acc[8 + 2 * d], acc[8 + 2 * d + 1]); }
+            __builtin_nontemporal_store(s0, reinterpret_cast<u32x4_t*>(e));
+            __builtin_nontemporal_store(s1, reinterpret_cast<u32x4_t*>(e + 1024));
+        }
         // ---- per-sample epilogue: sigma, SH colour (model/net_utils.py:154-169), sigmoid.  Register 4q + e of this lane
         //      is SH row n = 8q + 4h + e = 9 c + i (colour c, basis i); the two lane halves hold complementary rows.
         float bas[9];

@@ -28,7 +28,9 @@ class RenderSettings:
     sigma_default: float
     white_back: bool
     max_fine_per_ray: int = 128      # model/mc_nerf.py:630
-    precision: str = "f32"           # "f32": exact-fp32 MFMA; "f16x3": split-f16 MFMA (fp32-grade, ~3x faster chain kernels)
+    # "f32": exact-fp32 MFMA; "f16x3": split-f16 MFMA (fp32-grade: the 1e-4 parity modes); "f16" / "bf16": single-pass
+    # 16-bit MFMA with 2-byte workspaces (throughput modes, accuracy of the operand rounding: csrc/mcnerf_16.h)
+    precision: str = "f32"
 
     @property
     def samples_f(self):
@@ -77,7 +79,7 @@ class RenderTrainFn(torch.autograd.Function):
         prec = st.precision
         packed_c = ops.pack_weights(net_c, flat_c, precision=prec)
         out_c = torch.empty(N, st.samples_c, 4, dtype=torch.float32, device=dev)
-        save_c = ops.alloc_save(net_c, N * st.samples_c, dev) if need_grad else None
+        save_c = ops.alloc_save(net_c, N * st.samples_c, dev, precision=prec) if need_grad else None
         ops.mlp_fwd(net_c, flat_c, packed_c, rays_o, rays_d, owner.z_vals_c, jit, barf_w, out_c, save=save_c, precision=prec)
         rgb_c, depth_c, _, w_sel, wmax = ops.composite_fwd(out_c, rays_d, owner.z_vals_c, jit, eps_c,
                                                           None if only_coarse else eps_sel, st.white_back,
@@ -97,7 +99,7 @@ class RenderTrainFn(torch.autograd.Function):
         net_f = model_f.net
         flat_f = model_f.flat_params()
         packed_f = ops.pack_weights(net_f, flat_f, precision=prec)
-        save_f = ops.alloc_save(net_f, max_rows, dev) if need_grad else None
+        save_f = ops.alloc_save(net_f, max_rows, dev, precision=prec) if need_grad else None
         ops.mlp_fwd(net_f, flat_f, packed_f, rays_o, rays_d, owner.z_vals_f, jit, barf_w, out_f,
                     idx=idx, count=count, max_rows=max_rows, save=save_f, precision=prec)
         rgb_f, _, _, _, _ = ops.composite_fwd(out_f, rays_d, owner.z_vals_f, jit, eps_f, None, st.white_back)
@@ -135,8 +137,7 @@ class RenderTrainFn(torch.autograd.Function):
                 return
             net = model.net
             d_out, gmax = ops.composite_bwd(out, zgrid, jit, eps, d_rgb.contiguous(), st.white_back, want_gmax=True)
-            dy = torch.empty_like(save.act)
-            dsh = torch.empty_like(save.sh)
+            dy, dsh = ops.alloc_grad_ws(net, save, st.precision)
             ops.mlp_bwd(net, flat, packed, rays_o, rays_d, zgrid, jit, barf_w, out, d_out, save, dy, dsh,
                         d_o, d_d, idx=idx, count=count, max_rows=max_rows, precision=st.precision, gmax=gmax)
             rows = max_rows if idx is not None else N * zgrid.numel()

@@ -153,7 +153,7 @@ def raygen_bwd(pose: Tensor, kinv: Tensor, pix: Tensor, W: int, d_d: Tensor, d_o
 @dataclass
 class MlpSave:
     """Workspaces written by mlp_fwd(save=True) and consumed by mlp_bwd / mlp_dw.  In the 16-bit modes `act`, `enc`
-    and `mask` are byte buffers in the fragment-major layouts of csrc/mcnerf_16.h and `sh` is None."""
+    `sh` and `mask` are byte / word buffers in the fragment-major layouts of csrc/mcnerf_16.h."""
     capacity: int
     act: Tensor
     enc: Tensor
@@ -171,7 +171,7 @@ def alloc_save(net: Net, capacity: int, device, precision: str = "f32") -> MlpSa
         return MlpSave(capacity,
                        torch.empty(ws_bytes_16(net, capacity, 0), dtype=torch.uint8, device=device),
                        torch.empty(ws_bytes_16(net, capacity, 1), dtype=torch.uint8, device=device),
-                       None,
+                       torch.empty(ws_bytes_16(net, capacity, 4), dtype=torch.uint8, device=device),
                        torch.empty(ws_bytes_16(net, capacity, 2) // 4, dtype=torch.int32, device=device))
     return MlpSave(capacity,
                    torch.empty((net.depth + 2) * capacity * net.width, dtype=torch.float32, device=device),
@@ -190,7 +190,8 @@ def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
         _lib.call("mcnerf_mlp_fwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed.fwd, torch.uint8), _p(rays_o), _p(rays_d),
                   _p(zgrid), _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
                   _p(out), _p(save.act, torch.uint8) if save else None, save.capacity if save else 0,
-                  _p(save.enc, torch.uint8) if save else None, _p(save.mask, torch.int32) if save else None, _stream())
+                  _p(save.enc, torch.uint8) if save else None, _p(save.mask, torch.int32) if save else None,
+                  _p(save.sh, torch.uint8) if save else None, _stream())
         return
     _lib.call("mcnerf_mlp_fwd" if precision == "f32" else "mcnerf_mlp_fwd_f16x3", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
               _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
@@ -208,7 +209,7 @@ def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
     if is16(precision):
         _lib.call("mcnerf_mlp_bwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed.bwd, torch.uint8), _p(rays_o), _p(rays_d),
                   _p(zgrid), _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
-                  _p(out), _p(d_out), _p(save.mask, torch.int32), save.capacity, _p(save.enc, torch.uint8),
+                  _p(out), _p(d_out), _p(save.mask, torch.int32), save.capacity, _p(save.enc, torch.uint8), _p(save.sh, torch.uint8),
                   _p(dy, torch.uint8), _p(dsh, torch.uint8), _p(d_rays_o), _p(d_rays_d), _p(gmax, torch.int32), _stream())
         return
     args = [*net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
@@ -335,6 +336,24 @@ def decode_frags_16(buf: Tensor, n_slots: int, width: int, rows: int, precision:
     out = torch.empty_like(y)
     out[:, :, chan] = y
     return out[:, :rows]
+
+
+def decode_masks_16(mask: Tensor, n_slots: int, width: int, rows: int) -> Tensor:
+    """Lane-local ReLU bit masks of the 16-bit modes (csrc/mcnerf_16.h, mlp16_fwd.hip) -> bool [n_slots, rows, width].
+    Debug / test helper.  Word iw of lane (m, h) covers output tiles 2 iw, 2 iw + 1; inside a tile's 16 bits, packed word
+    i (registers 2 i, 2 i + 1) sits at bit 7 - i (+ 16 for the odd register), register r = channel 32 t + 8 (r >> 2) + 4 h + (r & 3)."""
+    mw = max(1, width // 64)
+    mk = mask.view(n_slots, -1, 2, 32, mw).cpu()                # [slot][tile][h][m][word]
+    tiles = mk.shape[1]
+    out = torch.zeros(n_slots, tiles, 32, width, dtype=torch.bool)
+    for t in range(width // 32):
+        for r in range(16):
+            i, odd = r >> 1, r & 1
+            bitpos = 8 * (t & 1) + 7 - i + 16 * odd
+            bit = ((mk[..., t >> 1] >> bitpos) & 1).bool()       # [slot][tile][h][m]
+            for h in range(2):
+                out[:, :, :, 32 * t + 8 * (r >> 2) + 4 * h + (r & 3)] = bit[:, :, h, :]
+    return out.reshape(n_slots, tiles * 32, width)[:, :rows]
 
 
 SPLIT_SCALE_X = 8.0      # MCN_SX of csrc/mcnerf_h.h

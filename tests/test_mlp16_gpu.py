@@ -128,3 +128,169 @@ def test_mlp16_fwd_indexed_multi_pass(gpu_device, precision):
     e = relerr(out[keep], ref[keep])
     print(f"[{precision}] indexed, {K} rows: out {e:.1e}")
     assert e < TOL_FWD[precision]
+
+
+# stated accuracy of the gradients (16-bit operands, fp32 accumulation): max|err| relative to the tensor's max|reference|
+# when the reference uses the same ReLU decisions, and relative L2 against the plain fp32 oracle (a pre-activation
+# within the operand rounding of zero can fall on either side: its gradient is discontinuous there)
+TOL_GRAD = {"f16": 4e-3, "bf16": 4e-2}
+TOL_GRAD_L2 = {"f16": 1e-1, "bf16": 3e-1}       # few hundred rows: a handful of flipped ReLUs dominate
+
+
+def masked_forward(p, nc, x_enc, dirs, masks):
+    """CorseFine_NeRF.forward (model/net_block.py:67-78) with the ReLU decisions supplied (masks[slot] bool [rows, W]):
+    identical to the oracle's forward wherever the decisions agree."""
+    F = torch.nn.functional
+    h = x_enc
+    for i in range(nc.depth):
+        if i in nc.skips:
+            h = torch.cat([x_enc, h], dim=-1)
+        h = F.linear(h, p[f"xyz_encoding_{i+1}.0.weight"], p[f"xyz_encoding_{i+1}.0.bias"]) * masks[i]
+    hs = F.linear(h, p["sigma.0.weight"], p["sigma.0.bias"]) * masks[nc.depth]
+    sigma = F.linear(hs, p["sigma.2.weight"], p["sigma.2.bias"])
+    hc = F.linear(h, p["sh.0.weight"], p["sh.0.bias"]) * masks[nc.depth + 1]
+    sh = F.linear(hc, p["sh.2.weight"], p["sh.2.bias"])
+    rgb = torch.sigmoid(O.eval_sh_deg2(sh.reshape(-1, 3, 9), dirs))
+    return torch.cat([sigma, rgb], dim=-1)
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+@pytest.mark.parametrize("width", [32, 64, 128, 256])
+def test_mlp16_fwd_bwd_indexed(gpu_device, width, precision):
+    """Fine-pass mode: (ray, sample) list + device count; forward, dX chain (ray gradients), dW against autograd of the
+    oracle -- (a) with the kernel's own ReLU decisions (tight), (b) plain oracle (relative L2)."""
+    ops = _ops()
+    dev = gpu_device
+    nc = NETS[width]
+    net = net_of(nc)
+    S, N = 40, 29
+    cfg = O.RenderCfg(samples=20, scale=2, coarse=nc, fine=nc, barf_mode=True, barf_start=0.2, barf_end=0.9)
+    step_r = 0.6
+    p0 = O.init_params(nc, 200 + width)
+    d0, o0 = make_rays(N, 9 + width)
+    g = torch.Generator().manual_seed(2)
+    jitter = torch.rand(N, 1, generator=g) * 0.2
+    zg = torch.linspace(cfg.near, cfg.far, S)
+    sel = torch.rand(N, S, generator=g) < 0.6
+    idx = torch.nonzero(sel)
+    K = idx.shape[0]
+    z = zg.unsqueeze(0) + jitter
+    r, j = idx[:, 0], idx[:, 1]
+    gout = torch.randn(K, 4, generator=g) * 1e-4            # gradient magnitudes of a mean-reduced loss
+
+    def reference(masks):
+        p = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+        d, o = d0.clone().requires_grad_(True), o0.clone().requires_grad_(True)
+        xyz = o[r] + d[r] * z[r, j].unsqueeze(-1)
+        enc = O.embed(xyz, step_r, cfg)
+        ref = O.mlp_forward(p, nc, enc, d[r]) if masks is None else masked_forward(p, nc, enc, d[r], masks)
+        (ref * gout).sum().backward()
+        return ref.detach(), p, d.grad, o.grad
+
+    flat = flat_params(nc, p0, dev)
+    packed = ops.pack_weights(net, flat, precision=precision)
+    cap = K + 17
+    idx_d = torch.zeros(cap, 2, dtype=torch.int32, device=dev)
+    idx_d[:K] = idx.to(torch.int32).to(dev)
+    count = torch.tensor([K], dtype=torch.int32, device=dev)
+    out = torch.full((N, S, 4), 7.0, device=dev)
+    save = ops.alloc_save(net, cap, dev, precision=precision)
+    bw = O.barf_weights(step_r, cfg).to(dev)
+    od, dd, zd, jd = o0.to(dev), d0.to(dev), zg.to(dev), jitter.reshape(-1).to(dev).contiguous()
+    ops.mlp_fwd(net, flat, packed, od, dd, zd, jd, bw, out, idx=idx_d, count=count, max_rows=cap, save=save, precision=precision)
+    ref, _, _, _ = reference(None)
+    got = out[r.to(dev), j.to(dev)]
+    assert relerr(got, ref) < TOL_FWD[precision]
+    assert torch.all(out[~sel.to(dev)] == 7.0)
+
+    d_out = torch.zeros(N, S, 4, device=dev)
+    d_out[r.to(dev), j.to(dev)] = gout.to(dev)
+    grads = torch.zeros_like(flat)
+    dy, dsh = ops.alloc_grad_ws(net, save, precision)
+    d_o = torch.zeros(N, 3, device=dev)
+    d_d = torch.zeros(N, 3, device=dev)
+    gmax = d_out.abs().max().reshape(1).view(torch.int32)
+    ops.mlp_bwd(net, flat, packed, od, dd, zd, jd, bw, out, d_out, save, dy, dsh, d_o, d_d,
+                idx=idx_d, count=count, max_rows=cap, precision=precision, gmax=gmax)
+    ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count, precision=precision, gmax=gmax)
+    torch.cuda.synchronize()
+
+    masks = ops.decode_masks_16(save.mask, nc.depth + 2, width, K)
+    _, hidden, _ = O.mlp_forward(p0, nc, O.embed(o0[r] + d0[r] * z[r, j].unsqueeze(-1), step_r, cfg), d0[r], return_hidden=True)
+    flips = sum(int((masks[l] != (h > 0)).sum()) for l, h in enumerate(hidden))
+    total = sum(h.numel() for h in hidden)
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max() / max(1e-30, float(b.abs().max())))
+
+    def l2(a, b):
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        return float((a - b).norm() / max(1e-30, float(b.norm())))
+    report = []
+    for tag, mk, metric, tol in (("same ReLU decisions", [m.float() for m in masks], rel, TOL_GRAD[precision]),
+                                 ("plain oracle, rel L2", None, l2, TOL_GRAD_L2[precision])):
+        _, p, dg, og = reference(mk)
+        e_o, e_d = metric(d_o, og), metric(d_d, dg)
+        worst, worst_name = 0.0, ""
+        for off, shp, name in zip(ops.param_offsets(net), net.shapes(), net.names()):
+            n = int(np.prod(shp))
+            e = metric(grads[off:off + n].view(shp), p[name].grad)
+            if e > worst:
+                worst, worst_name = e, name
+        report.append(f"{tag}: d_o {e_o:.1e} d_d {e_d:.1e} worst dW {worst:.1e} ({worst_name})")
+        assert e_o < tol and e_d < tol and worst < tol, (tag, e_o, e_d, worst_name, worst)
+    print(f"[{precision} W={width}] ReLU flips {flips}/{total} | " + " | ".join(report))
+
+
+@pytest.mark.parametrize("precision", ["f16"])
+@pytest.mark.parametrize("width", [128, 256])
+def test_mlp16_dw_at_scale(gpu_device, width, precision):
+    """The persistent dW kernel over ~0.4 M rows (thousands of tiles per workgroup, ring / DMA / transposed reads busy)
+    against a torch fp64 GEMM of the very operands it reads (decoded fragment-major workspaces)."""
+    import math
+    ops = _ops()
+    dev = gpu_device
+    nc = NETS[width]
+    net = net_of(nc)
+    D, W, skip = nc.depth, nc.width, nc.skips[0]
+    N, S = 3001, 128
+    rows = N * S
+    p = O.init_params(nc, 300 + width)
+    flat = flat_params(nc, p, dev)
+    packed = ops.pack_weights(net, flat, precision=precision)
+    d, o = make_rays(N, 77)
+    od, dd, zd = o.to(dev), d.to(dev), torch.linspace(1, 8, S, device=dev)
+    bw = torch.ones(10, device=dev)
+    out = torch.empty(N, S, 4, device=dev)
+    save = ops.alloc_save(net, rows, dev, precision=precision)
+    ops.mlp_fwd(net, flat, packed, od, dd, zd, None, bw, out, save=save, precision=precision)
+    d_out = torch.randn(N, S, 4, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 1e-3
+    gmax = d_out.abs().max().reshape(1).view(torch.int32)
+    dy, dsh = ops.alloc_grad_ws(net, save, precision)
+    d_o, d_d = torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev)
+    ops.mlp_bwd(net, flat, packed, od, dd, zd, None, bw, out, d_out, save, dy, dsh, d_o, d_d, precision=precision, gmax=gmax)
+    grads = torch.zeros_like(flat)
+    ops.mlp_dw(net, save, dy, dsh, grads, rows, precision=precision, gmax=gmax)
+    torch.cuda.synchronize()
+    sg = 2.0 ** (4 - math.ceil(math.log2(float(d_out.abs().max()))))
+    act = ops.decode_frags_16(save.act, D + 2, W, rows, precision).double()
+    dyv = ops.decode_frags_16(dy, D + 2, W, rows, precision).double() / sg
+    enc = ops.decode_frags_16(save.enc, 1, 64, rows, precision)[0][:, :63].double()
+    dshv = ops.decode_frags_16(dsh, 1, 32, rows, precision)[0].double() / sg
+    ref = {}
+    for l in range(D):
+        x = enc if l == 0 else (torch.cat([enc, act[l - 1]], 1) if l == skip else act[l - 1])
+        ref[f"xyz_encoding_{l + 1}.0.weight"] = dyv[l].t() @ x
+        ref[f"xyz_encoding_{l + 1}.0.bias"] = dyv[l].sum(0)
+    ref["sigma.0.weight"], ref["sigma.0.bias"] = dyv[D].t() @ act[D - 1], dyv[D].sum(0)
+    ref["sh.0.weight"], ref["sh.0.bias"] = dyv[D + 1].t() @ act[D - 1], dyv[D + 1].sum(0)
+    ref["sh.2.weight"], ref["sh.2.bias"] = dshv[:, :27].t() @ act[D + 1], dshv[:, :27].sum(0)
+    ref["sigma.2.weight"], ref["sigma.2.bias"] = dshv[:, 27:28].t() @ act[D], dshv[:, 27:28].sum(0)
+    for off, shp, name in zip(ops.param_offsets(net), net.shapes(), net.names()):
+        n = int(np.prod(shp))
+        got = grads[off:off + n].view(shp).double()
+        want = ref[name].view(shp)
+        scale = float(want.abs().max())
+        err = float((got - want).abs().max())
+        # fp32 accumulation of exact 16-bit products: only summation-order noise
+        assert math.isfinite(err) and err <= 2e-5 * max(scale, 1e-12) + 1e-9, f"{name}: err {err:.3e} scale {scale:.3e}"
