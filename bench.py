@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: train rays/sec of the MC-NeRF hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--precision P] [--also P,P,...] [--mode train|render]
 
 Workload = BASELINE.json configs[1]: Ball_Lego-shaped rig (110 cameras, 800x800), coarse 4x128 (64 samples)
 + fine 8x256 (128-sample grid), joint intrinsic/extrinsic optimisation stage (GLOBAL_OPTIM_EPOCH), synthetic
@@ -10,51 +10,83 @@ batch of R rays of one camera per rank: camera parametrisation -> ray generation
 selection -> fine MLP -> composite -> loss -> backward (composite, dX chain, dW, ray-gen) -> ONE gradient
 all-reduce (N > 1) -> RAdam step.  Inputs are resident in HBM before the timed region.
 
-For N > 1 launch as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+`--gpus N` with N > 1 and no torchrun environment: this process (which never touches the GPU) starts N fresh rank
+processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and waits for them; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks are the given processes.
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement"): the headline precision mode (`--precision`) timed for
+`--steps` steps, plus `by_precision` with the other modes of `--also` timed in the same run on fewer steps.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic FLOPs per evaluated sample, forward (SURVEY.md 8d): 2 x weight MACs
+# algorithmic FLOPs per evaluated sample, forward (SURVEY.md 8d): 2 x weight MACs.  The backward chain (dX) and the
+# weight gradients (dW) are one forward-equivalent each: a training step is 3x forward.
 F_FINE, F_COARSE = 2 * 629248, 2 * 101632
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0      # ibid., "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0              # ibid., "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
-# algorithmic HBM bytes per evaluated fine sample (DESIGN.md 3): fp32 operands the training step keeps for the
-# weight-gradient GEMMs (10 layer slots x 256 x 4 B) + encoded input (256 B) + SH coefficients (128 B) +
-# 1-bit ReLU masks (10 x 32 B) + output (16 B) + index (8 B)
-B_FWD = 10 * 1024 + 256 + 128 + 320 + 16 + 8
-B_BWD = 10 * 1024 + 128 + 320 + 256 + 128 + 32 + 8      # dY slots + dsh written; masks, enc, sh, out/d_out, index read
-B_DW = 2 * 1024 * 9 + 2 * (1024 + 256) + 2 * (1024 + 128)   # 9 WxW segments, 2 enc segments, sh.2 and sigma.2 segments
+# HBM bytes per evaluated fine sample that each kernel's CONTRACT makes it move (DESIGN.md 3).
+#  fp32 / split-f16 words: 10 layer slots x 256 x 4 B (+ encoding 256, SH 128, 1-bit masks 320, output 16, index 8)
+B32 = {"fwd": 10 * 1024 + 256 + 128 + 320 + 16 + 8,
+       "bwd": 10 * 1024 + 128 + 320 + 256 + 128 + 32 + 8,
+       "dw": 2 * 1024 * 9 + 2 * (1024 + 256) + 2 * (1024 + 128)}
+#  16-bit modes: 10 slots x 256 x 2 B (+ encoding 128, sh 64, masks 320, output 16, index 8)
+B16 = {"fwd": 10 * 512 + 128 + 64 + 320 + 16 + 8,
+       "bwd": 10 * 512 + 64 + 320 + 64 + 32 + 8,
+       "dw": 2 * 512 * 9 + 2 * (512 + 128) + 2 * (512 + 64)}
+DTYPE_TEXT = {"f32": "f32", "f16x3": "f16x3 (split-f16 MFMA operands: 3 MFMAs per product, fp32 accumulate/storage)",
+              "f16": "f16 (single-pass f16 MFMA operands, fp32 accumulate, 2-byte workspaces)",
+              "bf16": "bf16 (single-pass bf16 MFMA operands, fp32 accumulate, 2-byte workspaces)"}
+WORKLOAD = ("Ball_Lego-shaped 110-view 800x800, coarse 4x128 @64 + fine 8x256 @128-grid, GLOBAL_OPTIM stage, "
+            "fwd+bwd+allreduce+RAdam")
+
+
+def launch_ranks(args, argv):
+    """Parent of a self-launched multi-rank run: starts `--gpus` fresh rank processes (never initialises the GPU,
+    never re-execs), forwards their output, exits with the worst return code.  Mirrors what
+    utils/distributed_init.py:11-34 + `torchrun` do for the reference's main.py."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 class KernelTimer:
     """HIP-event timing of selected C-ABI calls on the stream they are launched on (torch's current stream)."""
+    BASES = ("mcnerf_mlp_fwd", "mcnerf_mlp_bwd", "mcnerf_mlp_dw")
 
     def __init__(self):
         self.records = {}
         self.enabled = False
 
     def install(self):
-        from mc_nerf_amd import _lib
+        import torch
+        from mc_nerf_amd import _lib, ops
         orig = _lib.call
         timer = self
 
         def timed(name, *args):
-            base = name.replace("_f16x3", "")
-            if not timer.enabled or base not in ("mcnerf_mlp_fwd", "mcnerf_mlp_bwd", "mcnerf_mlp_dw"):
+            base = name.replace("_f16x3", "").replace("_16", "")
+            if not timer.enabled or base not in timer.BASES:
                 return orig(name, *args)
-            key = (base, args[1])           # (entry point, net width)
+            key = (base[len("mcnerf_mlp_"):], args[1])           # (fwd | bwd | dw, net width)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             r = orig(name, *args)
@@ -63,60 +95,116 @@ class KernelTimer:
             return r
 
         _lib.call = timed
-        from mc_nerf_amd import ops
         ops._lib.call = timed
+
+    def reset(self):
+        self.records = {}
 
     def summary(self):
         return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.records.items()}
 
 
-def cpu_baseline(n_rays=1536):
-    """The oracle (a plain-PyTorch CPU port of the reference path, parity-pinned in tests/) timed on the host
-    cores on a bounded sample of the same workload: train forward+backward of cfg-2 nets on n_rays rays."""
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        phys = os.cpu_count()
+    return model, int(phys)
+
+
+def cpu_baseline(n_rays=2048, reps=3):
+    """The oracle (a plain-PyTorch CPU port of the reference path, parity-pinned to the reference in tests/) timed
+    on the host cores on a bounded sample of the same workload: cfg-2 nets, `n_rays` rays, one
+    full-size warm-up then best of `reps`, train (forward + backward) and render (no-grad) separately, all
+    physical cores."""
+    import torch
     from oracle import mcnerf_oracle as O
+    model, phys = cpu_info()
+    torch.set_num_threads(phys)
     torch.manual_seed(0)
     cfg = O.RenderCfg(samples=64, scale=2)
     pc = {k: v.requires_grad_(True) for k, v in O.init_params(cfg.coarse, 1).items()}
     pf = {k: v.requires_grad_(True) for k, v in O.init_params(cfg.fine, 2).items()}
+    g = torch.Generator().manual_seed(n_rays)
+    o = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1) * 3.0
+    d = torch.nn.functional.normalize(-o + 0.5 * torch.randn(n_rays, 3, generator=g), dim=-1)
+    jit = torch.rand(n_rays, 1, generator=g) * 7.0 / 64
+    e = [torch.randn(n_rays, s, generator=g) for s in (64, 64, 128)]
+    gt = torch.rand(n_rays, 3, generator=g)
+    k_fine = [0]
 
-    def run(n):
-        g = torch.Generator().manual_seed(n)
-        o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * 3.0
-        d = torch.nn.functional.normalize(-o + 0.5 * torch.randn(n, 3, generator=g), dim=-1)
-        jit = torch.rand(n, 1, generator=g) * 7.0 / 64
-        e = [torch.randn(n, s, generator=g) for s in (64, 64, 128)]
+    def train():
         t0 = time.perf_counter()
         r = O.render_rays_train(pc, pf, cfg, d, o, 1.0, jit, e[0], e[1], e[2])
-        O.rgb_loss(r["rgb_c"], r["rgb_f"], torch.rand(n, 3, generator=g)).backward()
-        return time.perf_counter() - t0, r["idx_f"].shape[0]
+        O.rgb_loss(r["rgb_c"], r["rgb_f"], gt).backward()
+        k_fine[0] = int(r["idx_f"].shape[0])
+        return time.perf_counter() - t0
 
-    run(128)
-    dt, k = run(n_rays)
-    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle train fwd+bwd, cfg-2 nets, {n_rays} rays, {k} fine samples, 1 timed run after warm-up"}
+    def render():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.render_rays_test(pc, pf, cfg, d, o, e[0], e[1], e[2])
+        return time.perf_counter() - t0
+
+    train()
+    t_train = min(train() for _ in range(reps))
+    render()
+    t_render = min(render() for _ in range(reps))
+    return {"value": n_rays / t_train, "unit": "rays/s", "cores": phys, "cpu_model": model, "kind": "port",
+            "render_value": n_rays / t_render, "render_unit": "rays/s (no-grad render_rays_test)",
+            "sample": f"oracle train fwd+bwd and no-grad render, cfg-2 nets, {n_rays} rays ({k_fine[0]} fine samples), "
+                      f"full-size warm-up then best of {reps}, {phys} threads"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=32768, help="rays per step per GPU (config `batch`)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
-                    help="MFMA mode of the MLP chain kernels: exact fp32, or split-f16 (fp32-grade, 3 f16 MFMAs per product)")
-    args = ap.parse_args()
+def parity_probe(precision, dev):
+    """Max |rgb - oracle| of one small train render in `precision` (256 rays, same draws): what the mode's arithmetic
+    costs against the fp32 CPU oracle on the bench's own nets (random init)."""
+    import torch
+    from mc_nerf_amd.model import NeRF_Model
+    from mc_nerf_amd import synthetic as S
+    from oracle import mcnerf_oracle as O
+    cfg = O.RenderCfg(samples=64, scale=2)
+    pc, pf = O.init_params(cfg.coarse, 1), O.init_params(cfg.fine, 2)
+    g = torch.Generator().manual_seed(0)
+    n = 256
+    o = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * 3.0
+    d = torch.nn.functional.normalize(-o + 0.4 * torch.randn(n, 3, generator=g), dim=-1)
+    jit = torch.rand(n, 1, generator=g) * 7.0 / 64
+    e = [torch.randn(n, s, generator=g) for s in (64, 64, 128)]
+    with torch.no_grad():
+        r = O.render_rays_train(pc, pf, cfg, d, o, 1.0, jit, e[0], e[1], e[2])
+        sp = S.make_sys_param(dev, samples=64, scale=2, batch=256, H=64, W=64, precision=precision)
+        m = NeRF_Model(sp).to(dev)
+        m.nerf_coarse.load_state_dict(pc)
+        m.nerf_fine.load_state_dict(pf)
+        rgb_c, rgb_f = m.render_rays_train(d.to(dev), o.to(dev), 0, 1.0, jitter=jit.to(dev), eps_c=e[0].to(dev),
+                                           eps_sel=e[1].to(dev), eps_f=e[2].to(dev))
+    return {"rgb_c_max_abs_err": float((rgb_c.cpu() - r["rgb_c"]).abs().max()),
+            "rgb_f_max_abs_err": float((rgb_f.cpu() - r["rgb_f"]).abs().max()),
+            "what": "train render of 256 rays, random-init cfg-2 nets, same draws, vs the fp32 CPU oracle"}
 
+
+def run_precision(precision, args, steps, warmup, rank, world, dev, timer, images_cache):
+    """Builds the cfg-2 model in `precision`, runs warmup + `steps` timed steps; returns the per-mode record."""
+    import torch
+    import torch.distributed as dist
     from mc_nerf_amd import distributed as D
-    rank, world, dev = D.init_distributed()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     from mc_nerf_amd import synthetic as S
     from mc_nerf_amd.model import MC_Model, MC_NeRF_Loss, RAdam
+    from mc_nerf_amd.data import DeviceImageSet
 
     torch.manual_seed(42 + rank)                   # main.py:274-277: seed + rank
     H = W = 800
-    sp = S.make_sys_param(dev, samples=64, scale=2, batch=args.rays, H=H, W=W, barf_mask=False, precision=args.precision)
+    sp = S.make_sys_param(dev, samples=64, scale=2, batch=args.rays, H=H, W=W, barf_mask=False, precision=precision)
     model = MC_Model(sp).to(dev)
     S.init_cameras_near_gt(model, noise=1e-3)
     loss_fn = MC_NeRF_Loss(sp)
@@ -124,16 +212,15 @@ def main():
     sync = D.FlatGradSync(model, world)
     sync.broadcast_parameters()
     C = model.train_numb
-    wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0])
-    wpts, pts = wpts.to(dev), pts.to(dev)
-    from mc_nerf_amd.data import DeviceImageSet
-    images = DeviceImageSet.synthetic(C, H, W, dev, channels=4, seed=7)     # uint8 RGBA resident in HBM (282 MB)
+    if "wpts" not in images_cache:
+        wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0])
+        images_cache["wpts"], images_cache["pts"] = wpts.to(dev), pts.to(dev)
+        images_cache["images"] = DeviceImageSet.synthetic(C, H, W, dev, channels=4, seed=7)     # uint8 RGBA resident in HBM (282 MB)
+    wpts, pts, images = images_cache["wpts"], images_cache["pts"], images_cache["images"]
     cams = D.shard_cameras(C, 0, rank, world, seed=42)
-    timer = KernelTimer()
-    timer.install()
-    counts = []
+    counts, ar_events = [], []
 
-    def step(i):
+    def step(i, timed):
         cam = cams[i % len(cams)]
         data = (images, torch.tensor([cam]), wpts, pts, wpts, pts)
         loss_dict, _, _, _ = model(data, 20, "GLOBAL_OPTIM_EPOCH", 0.6)
@@ -141,9 +228,16 @@ def main():
         opt.zero_grad(set_to_none=True)
         sync.prepare()
         loss.backward()
-        sync.sync()
+        if timed and world > 1:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            sync.sync()
+            b.record()
+            ar_events.append((a, b))
+        else:
+            sync.sync()
         opt.step()
-        if timer.enabled:
+        if timed:
             counts.append(model.nerf.last_selection[1].clone())
 
     def barrier():
@@ -152,13 +246,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    for i in range(warmup):
+        step(i, False)
     barrier()
+    timer.reset()
     timer.enabled = True
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i, True)
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
@@ -166,67 +261,191 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # parameters must be identical on every rank after synchronised steps (DDP invariant)
+    in_sync = True
+    if world > 1:
+        flat = torch.cat([p.detach().reshape(-1).float() for p in model.parameters()])
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi))
+    finite = bool(all(torch.isfinite(p).all() for p in model.parameters()))
+    k_mean = float(torch.stack(counts).float().mean())
+    ks = timer.summary()
+    rec = {"precision": precision, "value": args.rays * world * steps / dt, "unit": "rays/s", "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "fine_samples_per_ray": k_mean / args.rays, "finite": finite,
+           "kernel_ms": {f"mlp_{k}<{w}>": v for (k, w), v in sorted(ks.items())}}
+    if world > 1:
+        rec["allreduce_ms"] = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
+        rec["params_identical_across_ranks"] = in_sync
+    # roofline of the fine-net kernels with ALGORITHMIC work per launch over the HIP-event launch time
+    mfma_peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
+    contract = B16 if precision in ("f16", "bf16") else B32
+    per_call = {}
+    for k in ("fwd", "bwd", "dw"):
+        ms = ks.get((k, 256))
+        if ms:
+            tf = F_FINE * k_mean / (ms * 1e-3) / 1e12
+            gbs = contract[k] * k_mean / (ms * 1e-3) / 1e9
+            per_call[f"mlp_{k}<256>"] = {"ms": ms, "mfma_TFLOPs": tf, "mfma_frac": tf / mfma_peak, "contract_bytes_per_launch": contract[k] * k_mean,
+                                         "hbm_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS}
+    rec["per_call"] = per_call
+    rec["step_algorithmic_tflop"] = 3 * (F_FINE * k_mean + F_COARSE * args.rays * 64) / 1e12
+    rec["step_mfma_frac"] = rec["step_algorithmic_tflop"] / (dt / steps) / mfma_peak
+    del model, opt, sync
+    torch.cuda.empty_cache()
+    return rec, k_mean
 
+
+def pmc_traffic(precision, kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command
+    (scripts/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KB units, FETCH doubled on gfx950 as
+    MI355X_MICROARCH.md prescribes).  Pre-recorded, not measured in this run: returns (bytes | None, source)."""
+    cand = {"f16": "r02_pmc_traffic_f16.json", "bf16": "r02_pmc_traffic_bf16.json", "f16x3": "r01i_pmc_traffic.json", "f32": "r01c_pmc_traffic.json"}
+    path = os.path.join(ROOT, "profiles", cand.get(precision, ""))
+    if not os.path.isfile(path):
+        return None, None
+    names = {"f16": {"mlp_fwd<256>": "mlp16_fwd_kernel<256, true, false>", "mlp_bwd<256>": "mlp16_bwd_kernel<256, false>"},
+             "bf16": {"mlp_fwd<256>": "mlp16_fwd_kernel<256, true, true>", "mlp_bwd<256>": "mlp16_bwd_kernel<256, true>"},
+             "f16x3": {"mlp_fwd<256>": "mlp_fwd_h_kernel<256, true>", "mlp_bwd<256>": "mlp_bwd_h_kernel<256>"},
+             "f32": {"mlp_fwd<256>": "mlp_fwd_kernel<256, true>", "mlp_bwd<256>": "mlp_bwd_kernel<256>"}}[precision]
+    kern = json.load(open(path)).get("kernels", {})
+    k = names.get(kernel_key)
+    if k in kern:
+        return kern[k]["hbm_bytes_per_launch"], f"pre-recorded rocprofv3 PMC passes: profiles/{os.path.basename(path)} (N = 32768)"
+    return None, None
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
+    from mc_nerf_amd import distributed as D
+    rank, world, dev = D.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
+    if args.selftest:                              # launcher / rendezvous check without kernels (runs on CPU over gloo)
+        t = torch.ones(4, device=dev) * (rank + 1)
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "allreduce_ok": bool(float(t[0]) == world * (world + 1) / 2),
+                              "backend": dist.get_backend() if world > 1 else None}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    timer = KernelTimer()
+    timer.install()
+    cache = {}
+    if args.mode == "render":
+        out = run_render(args, rank, world, dev)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    head, k_mean = run_precision(args.precision, args, args.steps, args.warmup, rank, world, dev, timer, cache)
+    others = {}
+    for p in [q for q in args.also.split(",") if q and q != args.precision]:
+        s = max(5, args.steps // (10 if p == "f32" else 5))
+        others[p], _ = run_precision(p, args, s, 2, rank, world, dev, timer, cache)
     if rank == 0:
-        k_mean = float(torch.stack(counts).float().mean())
-        ks = timer.summary()
-        # dominant kernel = the slowest of the fused fine-net forward / backward chain / weight-gradient kernels.
-        # Both roofs are evaluated with ALGORITHMIC work per launch (FLOPs: 2 x MACs x evaluated samples; bytes:
-        # the operands the kernel's contract makes it move) over the HIP-event launch time; the binding one
-        # (larger fraction) is reported.
-        cand = {"mlp_fwd<256>": (ks.get(("mcnerf_mlp_fwd", 256)), B_FWD),
-                "mlp_bwd<256>": (ks.get(("mcnerf_mlp_bwd", 256)), B_BWD),
-                "mlp_dw<256>": (ks.get(("mcnerf_mlp_dw", 256)), B_DW)}
-        kern_ms = {k: v[0] for k, v in cand.items() if v[0]}
+        pc = head["per_call"]
+        # The dominant KERNEL is the longest single launch: the fused fine-net forward or backward chain (one launch each
+        # per call); mlp_dw is 15 launches per call, its aggregate is in `per_call`.  SURVEY 8(d) names the bound of this
+        # path as MFMA: `frac` is the MFMA fraction; the HBM roof (contract bytes and measured PMC bytes) sits beside it.
+        chain = {k: v for k, v in pc.items() if k != "mlp_dw<256>"}
+        dom = max(chain, key=lambda k: chain[k]["ms"])
         mfma_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
-
-        def roof_of(name):
-            secs = cand[name][0] * 1e-3
-            ach_tf = F_FINE * k_mean / secs / 1e12
-            ach_gbs = cand[name][1] * k_mean / secs / 1e9
-            if ach_tf / mfma_peak >= ach_gbs / PEAK_HBM_GBS:
-                r = {"bound": "mfma", "kernel": name, "achieved": ach_tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": ach_tf / mfma_peak}
-            else:
-                r = {"bound": "hbm", "kernel": name, "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS}
-            r["other_roof"] = {"mfma_TFLOPs": ach_tf, "mfma_frac": ach_tf / mfma_peak, "hbm_GBs": ach_gbs, "hbm_frac": ach_gbs / PEAK_HBM_GBS}
-            return r
-
-        # The dominant KERNEL is the longest single launch: the fused forward or the fused backward chain (one launch
-        # each per call).  mcnerf_mlp_dw is 15 launches per call (one per weight segment, <= 1.5 ms each); its
-        # aggregate is reported beside them in `per_call`.
-        dom = max((k for k in kern_ms if k != "mlp_dw<256>"), key=kern_ms.get)
-        roof = roof_of(dom)
-        per_call = {k: {kk: vv for kk, vv in roof_of(k).items() if kk in ("bound", "achieved", "unit", "frac")} for k in kern_ms}
-        # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes of this same command, collected and
-        # corrected as MI355X_MICROARCH.md prescribes (scripts/pmc_traffic.py; see profiles/*_pmc_traffic.json)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json" if args.precision == "f16x3" else "r01c_pmc_traffic.json")
-        if os.path.exists(tpath) and args.rays == 32768:
-            sfx = "_h" if args.precision == "f16x3" else ""
-            names = {"mlp_fwd<256>": f"mlp_fwd{sfx}_kernel<256, true>", "mlp_bwd<256>": f"mlp_bwd{sfx}_kernel<256>"}
-            kern = json.load(open(tpath))["kernels"]
-            if names[dom] in kern:
-                traffic = kern[names[dom]]["hbm_bytes_per_launch"]
-        total_rays = args.rays * world * args.steps
+        traffic, tsrc = pmc_traffic(args.precision, dom) if args.rays == 32768 else (None, None)
+        roof = {"bound": "mfma", "kernel": dom, "achieved": pc[dom]["mfma_TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
+                "frac": pc[dom]["mfma_frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": tsrc,
+                "other_roof": {"bound": "hbm", "contract_bytes_per_launch": pc[dom]["contract_bytes_per_launch"],
+                               "contract_GBs": pc[dom]["hbm_GBs"], "contract_frac": pc[dom]["hbm_GBs"] / PEAK_HBM_GBS,
+                               "pmc_bytes_per_launch": traffic,
+                               "pmc_over_contract": (traffic / pc[dom]["contract_bytes_per_launch"]) if traffic else None,
+                               "peak_GBs": PEAK_HBM_GBS},
+                "per_call": pc, "step_algorithmic_tflop": head["step_algorithmic_tflop"], "step_mfma_frac": head["step_mfma_frac"]}
         out = {
-            "metric": "train rays/sec (coarse+fine, 64+128 samples)", "value": total_rays / dt, "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "train rays/sec (coarse+fine, 64+128 samples)", "value": head["value"], "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f16x3 (split-f16 MFMA operands, fp32 accumulate/storage)", "data": "synthetic",
-            "config": {"workload": "Ball_Lego-shaped 110-view 800x800, coarse 4x128 @64 + fine 8x256 @128-grid, "
-                                   "GLOBAL_OPTIM stage, fwd+bwd+allreduce+RAdam",
-                       "precision": args.precision, "rays_per_step_per_gpu": args.rays, "fine_samples_per_ray": k_mean / args.rays,
+            "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
+            "config": {"workload": WORKLOAD, "precision": args.precision, "rays_per_step_per_gpu": args.rays,
+                       "fine_samples_per_ray": head["fine_samples_per_ray"],
                        "parallelism": f"dp{world} (cameras sharded, 1 flat all-reduce/step)"},
-            "roofline": dict(roof, traffic=traffic,
-                             traffic_unit="HBM bytes per launch (rocprofv3 PMC, profiles/*_pmc_traffic.json)",
-                             kernel_ms=kern_ms, per_call=per_call,
-                             step_algorithmic_tflops=3 * (F_FINE * k_mean + F_COARSE * args.rays * 64) / 1e12),
+            "roofline": roof,
+            "by_precision": {p: {k: v for k, v in r.items() if k != "precision"} for p, r in others.items()},
         }
+        for k in ("allreduce_ms", "params_identical_across_ranks", "finite"):
+            if k in head:
+                out[k] = head[k]
         if world == 1 and not args.no_cpu_baseline:
+            out["parity"] = parity_probe(args.precision, dev)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_render(args, rank, world, dev):
+    """No-grad demo / validation render (model/mc_nerf.py:106-122): whole 800x800 images of the
+    cfg-2 model in `batch`-ray chunks, uncapped fine selection; rays/s of render_rays_test."""
+    import torch
+    import torch.distributed as dist
+    from mc_nerf_amd import distributed as D
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd.model import MC_Model
+    torch.manual_seed(42 + rank)
+    H = W = 800
+    sp = S.make_sys_param(dev, samples=64, scale=2, batch=args.rays, H=H, W=W, barf_mask=False, precision=args.precision, mode=1)
+    model = MC_Model(sp).to(dev).eval()
+    cams = D.shard_cameras(model.train_numb, 0, rank, world, seed=42)
+    n_img = max(1, args.steps)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        model.render_image_device(cams[0])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n_img):
+            model.render_image_device(cams[i % len(cams)])
+        barrier()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    rays = H * W * n_img * world
+    return {"metric": "render rays/sec (no-grad, coarse+fine 64+128, uncapped selection)", "value": rays / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": n_img, "warmup": 1, "ms_per_step": dt / n_img * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
+            "config": {"workload": "Ball_Lego-shaped 800x800 images rendered in chunks of `batch` rays (demo / validation path)",
+                       "precision": args.precision, "rays_per_chunk": args.rays, "images": n_img}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=32768, help="rays per step per GPU (config `batch`)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f16", choices=["f32", "f16x3", "f16", "bf16"],
+                    help="MFMA mode of the MLP kernels: single-pass f16 / bf16 (throughput modes), split-f16 f16x3 or exact f32 "
+                         "(the 1e-4 parity modes)")
+    ap.add_argument("--also", default="f16x3,bf16,f32", help="other precision modes measured in the same run (by_precision)")
+    ap.add_argument("--mode", default="train", choices=["train", "render"])
+    ap.add_argument("--selftest", action="store_true", help="rendezvous / launcher check only (no kernels; works on CPU)")
+    args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -70,7 +70,10 @@ class FlatGradSync:
         self.net_sizes = [n.flat_params().numel() for n in self.nets]
         self.cam_params = [p for name, p in model.named_parameters() if not name.startswith("nerf.")]
         self.cam_sizes = [p.numel() for p in self.cam_params]
-        self.total = sum(self.net_sizes) + sum(self.cam_sizes)
+        self.n_grad = sum(self.net_sizes) + sum(self.cam_sizes)
+        # one flag per parameter tensor rides at the end of the same message: "some rank produced a gradient for it"
+        self.n_flags = sum(len(n.ordered_parameters()) for n in self.nets) + len(self.cam_params)
+        self.total = self.n_grad + self.n_flags
         dev = self.nets[0].flat_params().device
         self.arena = torch.zeros(self.total, dtype=torch.float32, device=dev)
 
@@ -84,6 +87,15 @@ class FlatGradSync:
             dist.broadcast(p.data, src=0)
 
     def prepare(self):
+        """Call before the step's backward().  Every managed parameter's `.grad` is dropped first: after `sync()` the
+        grads are VIEWS of the arena, and the HIP backward writes the next step's gradients into that same arena, so
+        a surviving `.grad` (zero_grad(set_to_none=False), a second backward) would make autograd's accumulation
+        add the arena to itself and silently double the gradient."""
+        for n in self.nets:
+            for p in n.ordered_parameters():
+                p.grad = None
+        for p in self.cam_params:
+            p.grad = None
         self.arena.zero_()
         self.model.nerf.grad_arena = self.arena
 
@@ -91,7 +103,7 @@ class FlatGradSync:
         """Call once after the step's single backward()."""
         nerf = self.model.nerf
         used = getattr(nerf, "grad_arena_used", False)
-        pairs = []
+        pairs, have = [], []
         o = 0
         for n, sz in zip(self.nets, self.net_sizes):
             for p, po in zip(n.ordered_parameters(), n._offsets):
@@ -99,18 +111,25 @@ class FlatGradSync:
                 if p.grad is not None and not used:      # backward ran without the arena: gather
                     v.copy_(p.grad)
                 pairs.append((p, v))
+                have.append(1.0 if p.grad is not None else 0.0)
             o += sz
         for p, sz in zip(self.cam_params, self.cam_sizes):
             v = self.arena[o:o + sz].view(p.shape)
             if p.grad is not None:
                 v.copy_(p.grad)
             pairs.append((p, v))
+            have.append(1.0 if p.grad is not None else 0.0)
             o += sz
         if self.world > 1:
+            self.arena[self.n_grad:].copy_(torch.tensor(have, dtype=torch.float32), non_blocking=True)
             dist.all_reduce(self.arena, op=dist.ReduceOp.SUM)     # the step's ONE collective
-            self.arena.div_(self.world)
-        for p, v in pairs:
-            if p.grad is not None:
-                p.grad = v
+            self.arena[:self.n_grad].div_(self.world)
+            have = self.arena[self.n_grad:].tolist()              # (tiny D2H after the collective; the optimiser step follows anyway)
+        # A reduced slice becomes its parameter's gradient whenever ANY rank produced one (DDP semantics: a parameter unused
+        # on this rank but used elsewhere still receives the averaged gradient, otherwise the replicas diverge); parameters
+        # without a gradient on every rank (a stage that does not touch them) keep `.grad = None`, so the optimiser
+        # skips them exactly as in the reference.
+        for (p, v), h in zip(pairs, have):
+            p.grad = v if h > 0 else None
         nerf.grad_arena = None
         nerf.grad_arena_used = False

@@ -195,49 +195,90 @@ class NeRF_Model(nn.Module):
         save_path = os.path.join(Path(self.weights_pth), Path("train"))
         os.makedirs(save_path, exist_ok=True)
         stamp = time.strftime("%Y-%m-%d-%H-%M-%S", time.localtime())
-        name = "{}-EPOCH-{}-{}.ckpt".format(self.data_name, epoch, stamp)
-        self.ckpt_path = os.path.join(save_path, name)
+        self.model_name = "{}-EPOCH-{}-{}.ckpt".format(self.data_name, epoch, stamp)        # reference attributes (:743-744)
+        self.file_path = os.path.join(save_path, self.model_name)
+        self.ckpt_path = self.file_path
         if _rank() == 0:
-            module = model.module if hasattr(model, "module") else model
-            torch.save({"model_nerf": module.state_dict()}, self.ckpt_path)
-            logging.info("Save EPOCH {} weights: {}".format(epoch, self.ckpt_path))
-        return self.ckpt_path
+            # `model` is what main.py passes: the (possibly DDP-wrapped) MC_Model; its state_dict() keys are the
+            # checkpoint's (DDP's "module." prefix included, exactly as the reference writes them)
+            torch.save({"model_nerf": model.state_dict()}, self.file_path)
+            logging.info("Save model:{}".format(self.model_name))
+        return self.file_path
 
     @staticmethod
     def rewrite_nerf_ckpt(ckpt, coarse=False):
-        """{'model_nerf': MC_Model.state_dict()} -> state dict of one net (prefix stripping)."""
-        prefix = "nerf.nerf_coarse." if coarse else "nerf.nerf_fine."
+        """{'model_nerf': MC_Model.state_dict()} -> state dict of one net: the key suffix after the `nerf_coarse` /
+        `nerf_fine` path component (reference :815-837; also strips DDP's `module.` prefix that way)."""
+        name = "nerf_coarse" if coarse else "nerf_fine"
         out = {}
         for k, v in ckpt["model_nerf"].items():
-            if k.startswith(prefix):
-                out[k[len(prefix):]] = v
+            parts = k.split(".")
+            if name in parts:
+                out[".".join(parts[parts.index(name) + 1:])] = v
         return out
 
     @staticmethod
     def cal_psnr(pred, gt):
         return -10.0 * torch.log10(torch.mean((pred - gt) ** 2))
 
+    psnr_score = cal_psnr          # reference name (:839-848)
+
     @torch.no_grad()
-    def valid_train(self, epoch, rays_valid, epoch_type=None):
-        """Chunked render of one validation view with the current weights (reference :754-813 renders
-        with weights re-loaded from the checkpoint just written; the values are identical).
-        Returns (rgb [HW,3], psnr) on rank 0, None elsewhere; other ranks wait at the barrier."""
-        result = None
+    def render_chunked(self, rays_d, rays_o, model_coarse, model_fine, chunk=None):
+        """render_rays_test over all rays in `chunk`-ray pieces (the demo / validation hot loop, :106-122, 778-786);
+        everything stays on the device.  -> rgb [M,3], depth [M,1], opacity [M,1]"""
+        chunk = chunk or self.batch_test
+        M = rays_d.shape[0]
+        rgb = torch.empty(M, 3, dtype=torch.float32, device=rays_d.device)
+        depth = torch.empty(M, 1, dtype=torch.float32, device=rays_d.device)
+        opac = torch.empty(M, 1, dtype=torch.float32, device=rays_d.device)
+        for i in range(0, M, chunk):
+            r, d, o = self.render_rays_test(rays_d[i:i + chunk], rays_o[i:i + chunk], model_coarse, model_fine)
+            rgb[i:i + chunk], depth[i:i + chunk], opac[i:i + chunk] = r, d, o
+        return rgb, depth, opac
+
+    @torch.no_grad()
+    def valid_train(self, epoch, val_data, epoch_type):
+        """Reference :754-813: on rank 0 re-load the checkpoint just written by save_model into fresh nets, render the
+        validation view in `batch` chunks, write the image / ground truth / depth PNGs and log the PSNR (computed on the
+        device; SSIM / LPIPS are third-party metrics outside the hot path); the other ranks wait at the barrier.
+        Returns 0 in the camera-only stage, None otherwise (as the reference); the render is kept in
+        `self.last_validation` = dict(rgb, depth, psnr) for callers that want it."""
+        if epoch_type in ["CAM_PARAM_EPOCH"]:
+            return 0
         if _rank() == 0:
-            rays_d, rays_o, gt = rays_valid
-            gt = gt.reshape(-1, 3)
-            chunks = []
-            for i in range(0, rays_d.shape[0], self.batch_test):
-                rgb, _, _ = self.render_rays_test(rays_d[i:i + self.batch_test], rays_o[i:i + self.batch_test],
-                                                  self.nerf_coarse, self.nerf_fine)
-                chunks.append(rgb)
-            rgb = torch.cat(chunks, 0)
-            psnr = self.cal_psnr(rgb, gt.to(rgb.device))
-            logging.info("EPOCH {} validation PSNR: {:.3f}".format(epoch, float(psnr)))
-            result = (rgb, psnr)
+            rays_d, rays_o, gt_rgbs = val_data
+            ckpt = torch.load(self.file_path, map_location=self.device)
+            logging.info("Loading model: {}".format(self.model_name))
+            val_c = CorseFine_NeRF(self.sys_param, type="coarse").to(self.device)
+            val_f = CorseFine_NeRF(self.sys_param, type="fine").to(self.device)
+            val_c.load_state_dict(self.rewrite_nerf_ckpt(ckpt, coarse=True))
+            val_f.load_state_dict(self.rewrite_nerf_ckpt(ckpt, coarse=False))
+            val_c.eval(), val_f.eval()
+            rgb, depth, _ = self.render_chunked(rays_d, rays_o, val_c, val_f)
+            gt = gt_rgbs.reshape(-1, 3).to(rgb.device)
+            psnr = self.cal_psnr(rgb, gt)
+            self.last_validation = {"rgb": rgb, "depth": depth, "psnr": psnr}
+            logging.info("PSNR:{}".format(float(psnr)))
+            if rgb.shape[0] == self.render_h * self.render_w:
+                self._save_validation_images(epoch, rgb, gt, depth)
         if dist.is_available() and dist.is_initialized():
             dist.barrier()
-        return result
+        return None
+
+    def _save_validation_images(self, epoch, rgb, gt, depth):
+        try:
+            from PIL import Image
+        except ImportError:                                     # image files are a convenience, not part of the path
+            return
+        base = os.path.join(Path(self.train_img_pth), Path(self.data_name))
+        os.makedirs(base, exist_ok=True)
+
+        def u8(t, ch):
+            return (t.reshape(self.render_h, self.render_w, ch).clamp(0, 1) * 255).round().to(torch.uint8).cpu().numpy()
+        Image.fromarray(u8(rgb, 3), "RGB").save(os.path.join(base, "epoch_{}.png".format(epoch)))
+        Image.fromarray(u8(gt, 3), "RGB").save(os.path.join(base, "epoch_{}_gt.png".format(epoch)))
+        Image.fromarray(u8(depth, 1)[..., 0], "L").save(os.path.join(base, "epoch_{}_depth.png".format(epoch)))
 
 
 # ============================================================================ multi-camera model
@@ -325,13 +366,15 @@ class MC_Model(nn.Module):
         return loss_dict, intr_show, pose_show, rays_valid
 
     @torch.no_grad()
-    def _forward_demo(self, img_id):
+    def render_image_device(self, img_id):
+        """The demo render of one test camera (:106-122) with the result left on the device."""
         rays_d, rays_o = self.get_rays(self.test_pose, img_id, self.intr_test_inv.to(self.device))
-        rgbs, depth, opacity = [], [], []
-        for i in range(0, rays_d.shape[0], self.batch):
-            r, d, o = self.nerf(rays_d[i:i + self.batch], rays_o[i:i + self.batch])
-            rgbs.append(r.cpu()); depth.append(d.cpu()); opacity.append(o.cpu())
-        return torch.cat(rgbs, 0), torch.cat(depth, 0), torch.cat(opacity, 0)
+        return self.nerf.render_chunked(rays_d, rays_o, self.nerf.nerf_coarse, self.nerf.nerf_fine, chunk=self.batch)
+
+    @torch.no_grad()
+    def _forward_demo(self, img_id):
+        rgb, depth, opacity = self.render_image_device(img_id)
+        return rgb.cpu(), depth.cpu(), opacity.cpu()
 
     # ------------------------------------------------------------------ rays (:124-145, 327-345)
     def get_rays(self, pose, img_id, intr_inv):
@@ -436,5 +479,11 @@ class MC_Model(nn.Module):
             epoch, float(intr_err[:, 0, 0].mean()), float(intr_err[:, 1, 1].mean()), float(intr_err[:, 0, 2].mean()),
             float(intr_err[:, 1, 2].mean()), float(pose_err[..., :3].mean()), float(pose_err[..., 3].mean())))
 
-    def show_RT_est_results(self, epoch, mode="train"):
-        logging.info("EPOCH {}: camera frusta plot skipped (visualisation is out of scope)".format(epoch))
+    def show_RT_est_results(self, epoch, epoch_type=None, mode="epoch", show_info=True):
+        """Reference signature (:388); main.py:94 calls show_RT_est_results(epoch, epoch_type, mode='epoch').  The
+        reference aligns the estimated poses to the ground truth and plots the camera frusta; here the alignment-free
+        pose error is logged (plotting is outside the hot path)."""
+        if show_info and hasattr(self, "pose_adj"):
+            err = (self.gt_pose - self.pose_adj.detach()).abs()
+            logging.info("EPOCH {} [{}] pose |R err| {:.5f} |t err| {:.5f}".format(epoch, epoch_type, float(err[..., :3].mean()),
+                                                                                   float(err[..., 3].mean())))

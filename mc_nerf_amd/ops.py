@@ -108,24 +108,23 @@ def is16(precision: str) -> bool:
     return precision in DTYPE16
 
 
-@dataclass
-class Packed16:
-    """The two 16-bit fragment streams of one net (forward order / transposed backward order)."""
-    fwd: Tensor
-    bwd: Tensor
+def packed16_split(net: Net, packed: Tensor):
+    """The 16-bit modes keep both fragment streams of a net in ONE byte tensor: (forward stream, backward stream) views."""
+    nf = int(_lib.lib().mcnerf_packed_bytes_16(*net.triple, 0))
+    return packed[:nf], packed[nf:]
 
 
 def pack_weights(net: Net, params: Tensor, packed=None, precision: str = "f32"):
     """Packed weights for the given precision mode: one fp32-sized buffer (f32: fp32 fragments, f16x3: split-f16
-    fragments) or, in the 16-bit modes, a Packed16 pair of fragment streams."""
+    fragments) or, in the 16-bit modes, one byte tensor holding the forward and the backward fragment stream."""
     assert precision in PRECISIONS
     if is16(precision):
         if packed is None:
             l = _lib.lib()
-            packed = Packed16(torch.empty(int(l.mcnerf_packed_bytes_16(*net.triple, 0)), dtype=torch.uint8, device=params.device),
-                              torch.empty(int(l.mcnerf_packed_bytes_16(*net.triple, 1)), dtype=torch.uint8, device=params.device))
-        _lib.call("mcnerf_pack_weights_16", *net.triple, _p(params), _p(packed.fwd, torch.uint8), _p(packed.bwd, torch.uint8),
-                  DTYPE16[precision], _stream())
+            packed = torch.empty(int(l.mcnerf_packed_bytes_16(*net.triple, 0)) + int(l.mcnerf_packed_bytes_16(*net.triple, 1)),
+                                 dtype=torch.uint8, device=params.device)
+        pf, pb = packed16_split(net, packed)
+        _lib.call("mcnerf_pack_weights_16", *net.triple, _p(params), _p(pf, torch.uint8), _p(pb, torch.uint8), DTYPE16[precision], _stream())
         return packed
     if packed is None:
         packed = torch.empty(packed_count(net), dtype=torch.float32, device=params.device)
@@ -187,7 +186,7 @@ def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
     n_rays, S = rays_d.shape[0], zgrid.numel()
     assert out.numel() == n_rays * S * 4
     if is16(precision):
-        _lib.call("mcnerf_mlp_fwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed.fwd, torch.uint8), _p(rays_o), _p(rays_d),
+        _lib.call("mcnerf_mlp_fwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed16_split(net, packed)[0], torch.uint8), _p(rays_o), _p(rays_d),
                   _p(zgrid), _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
                   _p(out), _p(save.act, torch.uint8) if save else None, save.capacity if save else 0,
                   _p(save.enc, torch.uint8) if save else None, _p(save.mask, torch.int32) if save else None,
@@ -207,7 +206,7 @@ def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
             precision: str = "f32", gmax: Optional[Tensor] = None) -> None:
     n_rays, S = rays_d.shape[0], zgrid.numel()
     if is16(precision):
-        _lib.call("mcnerf_mlp_bwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed.bwd, torch.uint8), _p(rays_o), _p(rays_d),
+        _lib.call("mcnerf_mlp_bwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed16_split(net, packed)[1], torch.uint8), _p(rays_o), _p(rays_d),
                   _p(zgrid), _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
                   _p(out), _p(d_out), _p(save.mask, torch.int32), save.capacity, _p(save.enc, torch.uint8), _p(save.sh, torch.uint8),
                   _p(dy, torch.uint8), _p(dsh, torch.uint8), _p(d_rays_o), _p(d_rays_d), _p(gmax, torch.int32), _stream())

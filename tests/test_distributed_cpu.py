@@ -142,5 +142,32 @@ def test_single_process_sync_is_identity():
     for n, p in model.named_parameters():
         if g[n] is not None:
             assert torch.equal(p.grad, g[n])
+    # one message: every gradient + one "some rank has a gradient" flag per parameter tensor
     assert sync.arena.numel() == sum(p.numel() for _, p in model.named_parameters() if not _.startswith("nerf.")) + \
-        sum(n.flat_params().numel() for n in sync.nets)
+        sum(n.flat_params().numel() for n in sync.nets) + len(list(model.parameters()))
+    # stage 1 touches no NeRF parameter: they stay without a gradient, as in the reference (the optimiser skips them)
+    assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("nerf."))
+
+
+def test_prepare_drops_stale_grads_no_doubling():
+    """after sync() the grads are views of the arena; a following backward into the same arena must not be
+    accumulated onto them (zero_grad(set_to_none=False) keeps `.grad` tensors alive)."""
+    from mc_nerf_amd import distributed as D
+    from mc_nerf_amd import synthetic as S
+    model, sp = _build_model()
+    S.init_cameras_near_gt(model)
+    sync = D.FlatGradSync(model, 1)
+    calib = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0])
+    sync.prepare()
+    g1 = _stage1_grads(model, sp, 3, calib)
+    sync.sync()
+    first = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    for p in model.parameters():                     # what optimizer.zero_grad(set_to_none=False) does
+        if p.grad is not None:
+            p.grad.zero_()
+    sync.prepare()
+    _stage1_grads(model, sp, 3, calib)
+    sync.sync()
+    for n, p in model.named_parameters():
+        if n in first:
+            assert torch.allclose(p.grad, first[n], rtol=0, atol=1e-7), n      # same step twice: same gradient, not 2x

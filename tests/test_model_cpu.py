@@ -129,3 +129,51 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     m2 = MC_Model(sp)
     m2.load_state_dict(ref_sd)
     assert torch.equal(m2.nerf.nerf_fine.flat_params()[:5], m.nerf.nerf_fine.flat_params()[:5])
+
+
+def test_main_py_epoch_end_call_sequence(tmp_path):
+    """The reference's train loop ends every epoch with (main.py:92-95)
+        mc_nerf.nerf.save_model(model, epoch); mc_nerf.show_estimate_param(intr, pose, epoch, epoch_type);
+        mc_nerf.show_RT_est_results(epoch, epoch_type, mode='epoch'); mc_nerf.nerf.valid_train(epoch, rays_valid, epoch_type)
+    with exactly these arguments: the hooks must accept them (a signature drift here raises a TypeError at
+    the end of the first epoch)."""
+    from mc_nerf_amd.model import MC_Model
+    sp = S.make_sys_param("cpu", samples=32, scale=2, batch=16, H=8, W=8, coarse=(4, 32, [2]), fine=(8, 64, [4]),
+                          root_weight=str(tmp_path), demo_render_pth=str(tmp_path))
+    m = MC_Model(sp)
+    K, pose, _ = m.add_weights2param(True, True, True)
+    m.intr_adj, m.pose_adj = K, pose
+    intr_show = [m.intr_train.detach(), K.detach()]
+    pose_show = [m.gt_pose.detach(), pose.detach()]
+    rays_valid = [torch.zeros(64, 3), torch.zeros(64, 3), torch.zeros(1, 64, 3)]
+    for epoch_type in ("CAM_PARAM_EPOCH",):
+        m.nerf.save_model(m, 0)
+        assert m.nerf.file_path.endswith(m.nerf.model_name) and m.nerf.model_name.endswith(".ckpt")      # reference attributes
+        m.show_estimate_param(intr_show, pose_show, 0, epoch_type)
+        m.show_RT_est_results(0, epoch_type, mode='epoch')
+        assert m.nerf.valid_train(0, rays_valid, epoch_type) == 0          # camera-only stage: no render (mc_nerf.py:755-756)
+    import inspect
+    sig = inspect.signature(m.show_RT_est_results)
+    assert list(sig.parameters) == ["epoch", "epoch_type", "mode", "show_info"]
+    assert list(inspect.signature(m.nerf.valid_train).parameters) == ["epoch", "val_data", "epoch_type"]
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` (the driver's scaling form) must start 2 ranks itself; --selftest runs the launcher
+    and the rendezvous over gloo without kernels."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCNERF_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["allreduce_ok"] and out["backend"] == "gloo"
+    # a world size that disagrees with --gpus is an error, not a silent 1-rank run
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest"], env=env2,
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "--gpus 2" in (r2.stderr + r2.stdout)
