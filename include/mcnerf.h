@@ -185,6 +185,15 @@ int mcnerf_select_fine(const float* w_sel, const uint32_t* wmax_bits, float thre
 /* The random cap of model/mc_nerf.py:630-632: idx_out[i] = idx_in[perm[i]], i < keep; *count = keep. */
 int mcnerf_cap_gather(const int32_t* idx_in, const int64_t* perm, int keep, int32_t* idx_out, int32_t* count, void* stream);
 
+/* The same cap with the random subset drawn ON THE DEVICE (no host synchronisation): when *count > keep a uniformly
+ * random subset of `keep` entries of idx_in[0 .. *count) is written to idx_out (order unspecified, as the order of the
+ * list never reaches a result) and *count_out = keep; otherwise all *count entries are copied.  Entry i is ranked by a
+ * 32-bit hash of (*seed, i); *seed is a device word (drawn from torch's device generator by the host classes).
+ * ws: mcnerf_cap_ws_words() uint32 of scratch. */
+long long mcnerf_cap_ws_words(void);
+int mcnerf_cap_random(const int32_t* idx_in, const int32_t* count, int max_rows, int keep, const uint32_t* seed,
+                      uint32_t* ws, int32_t* idx_out, int32_t* count_out, void* stream);
+
 /* Ground-truth colours of n pixels of ONE uint8 image resident in HBM:
  * image [H*W, channels] (channels 3 = RGB, 4 = RGBA composited on white as data/data_read.py:130-137),
  * pix [n] int64 -> out [n,3] fp32.  Replaces the per-step H2D image copy + gather (model/mc_nerf.py:379, 80). */

@@ -52,6 +52,8 @@ SIGNATURES = {
     "mcnerf_composite_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "mcnerf_select_fine": (_I, [_P, _P, c_float, _I, _I, _I, c_float, _P, _P, _P, _P, _P, _P]),
     "mcnerf_cap_gather": (_I, [_P, _P, _I, _P, _P, _P]),
+    "mcnerf_cap_ws_words": (_L, []),
+    "mcnerf_cap_random": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "mcnerf_gather_gt": (_I, [_P, _I, _P, _I, _P, _P]),
     "mcnerf_camera_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "mcnerf_camera_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -291,6 +291,13 @@ int mcnerf_cap_gather(const int32_t* idx_in, const int64_t* perm, int keep, int3
     return check("mcnerf_cap_gather", mcn_launch_cap_gather((const int2*)idx_in, (const long long*)perm, keep, (int2*)idx_out, count, (hipStream_t)stream));
 }
 
+long long mcnerf_cap_ws_words(void) { return MCN_CAP_WS; }
+int mcnerf_cap_random(const int32_t* idx_in, const int32_t* count, int max_rows, int keep, const uint32_t* seed,
+                      uint32_t* ws, int32_t* idx_out, int32_t* count_out, void* stream) {
+    REQ(idx_in && count && seed && ws && idx_out && count_out && max_rows >= 0 && keep >= 0, "mcnerf_cap_random");
+    return check("mcnerf_cap_random", mcn_launch_cap_random((const int2*)idx_in, count, max_rows, keep, seed, ws, (int2*)idx_out, count_out, (hipStream_t)stream));
+}
+
 int mcnerf_gather_gt(const uint8_t* image, int channels, const int64_t* pix, int n, float* out, void* stream) {
     REQ(image && pix && out && n >= 0 && (channels == 3 || channels == 4), "mcnerf_gather_gt");
     return check("mcnerf_gather_gt", mcn_launch_gather_gt(image, channels, (const long long*)pix, n, out, (hipStream_t)stream));

@@ -201,6 +201,17 @@ __device__ __forceinline__ unsigned mcn16_pkmul(unsigned a, unsigned b) {
     return r;
 }
 
+// workspace store of one fragment / mask vector (non-temporal: written once, read by a later kernel; keeps the packed
+// weights in L2).  (ABL16_* = timing-only ablation builds)
+template <class V>
+__device__ __forceinline__ void mcn16_ws_store(const V& v, V* p) {
+#if defined(ABL16_PLAINSTORE)
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
 // ---- the shared weight ring -------------------------------------------------------------------------------------
 // Every wave issues the same two 1 KiB pieces per slab; all of a wave's LDS-DMA operations are these pieces, in program
 // order, so "my pieces of slab G have landed" == at most 2 * (AHEAD - 1) younger pieces outstanding.  Other vector-memory
@@ -231,6 +242,12 @@ __device__ __forceinline__ void mcn16_dma16(const char* gsrc, unsigned lds_dst) 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// 256-byte piece: one dword per lane (LDS destination = lds_dst + lane * 4)
+__device__ __forceinline__ void mcn16_dma4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void mcn16_ring_issue(Mcn16Ring& r, char* ring_lds) {
     const char* s = r.src + (size_t)r.src_slab * (MCN16_SLAB * 1024);
     const unsigned d = r.lds_base + r.issue_slot * (MCN16_SLAB * 1024) + r.lds_piece;
@@ -242,7 +259,11 @@ __device__ __forceinline__ void mcn16_ring_issue(Mcn16Ring& r, char* ring_lds) {
 // Synchronise the next slab: wait for this wave's pieces of it, rendezvous (every wave's pieces have landed), refill
 // the ring AHEAD slabs further on.  r.next_off = the slab's LDS byte offset.
 __device__ __forceinline__ void mcn16_ring_sync(Mcn16Ring& r, char* ring_lds) {
+#ifdef MCN16_EXP_VMCNT      // (timing experiment only: a larger count is NOT safe in general)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MCN16_EXP_VMCNT) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (MCN16_AHEAD - 1)) : "memory");
+#endif
     r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
     r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
     mcn16_ring_issue(r, ring_lds);

@@ -14,7 +14,9 @@ template <int W>
 struct Bwd16Smem {
     static constexpr int oW2 = MCN16_RING * MCN16_SLAB * 1024;     // sigma.2 weight row [W] fp32
     static constexpr int oBarf = oW2 + W * 4;                      // BARF weights [10] (+ pad)
-    static constexpr int total = oBarf + 16 * 4;
+    static constexpr int MW = W >= 64 ? W / 64 : 1;                 // mask dwords per lane and slot
+    static constexpr int oMask = oBarf + 16 * 4;                    // per wave: 3 buffers of [MW][64] dwords (ReLU bits, fetched ahead by LDS-DMA)
+    static constexpr int total = oMask + MCN16_WAVES * 3 * MW * 256;
 };
 
 // GEMM over one segment of NTILES output tiles x KSTEPS contraction steps (B fragments `in`), software-pipelined like
@@ -57,8 +59,8 @@ __device__ __forceinline__ void mcn16_bwd_seg(Mcn16Ring& ring, char* smem, int l
             if (i < 4) o0[i] = w; else o1[i - 4] = w;
             if (i == 7) { out[2 * t] = o0; out[2 * t + 1] = o1; }
         } else if (MODE != 0) {
-            if (i == 8) __builtin_nontemporal_store(o0, reinterpret_cast<u32x4_t*>(save_lane + (2 * t) * 1024));
-            else __builtin_nontemporal_store(o1, reinterpret_cast<u32x4_t*>(save_lane + (2 * t + 1) * 1024));
+            if (i == 8) mcn16_ws_store(o0, reinterpret_cast<u32x4_t*>(save_lane + (2 * t) * 1024));
+            else mcn16_ws_store(o1, reinterpret_cast<u32x4_t*>(save_lane + (2 * t + 1) * 1024));
         }
     };
     cur.cur = ring.next_off;
@@ -127,16 +129,35 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
         const long long gc = valid ? g : total - 1;
         const unsigned* mask_lane = a.mask_ws + ((size_t)tile * 64 + lane) * MW;
         char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)tile * KS * 1024 + lane * 16;
-        auto load_mask = [&](unsigned (&mk)[MW], int slot) {
+        // ReLU bits of a slot are fetched by LDS-DMA into one of this wave's three buffers well ahead of their use (an
+        // ordinary load in the layer loop makes hipcc wait vmcnt(0) at its use: a full drain of the weight ring and of
+        // the workspace stores once per layer).  Slot x <= D-1 lives in buffer (D + 1 - x) % 3; D in 0, D + 1 in 1.
+        // Issue points are at least two segments ahead, so the counted ring waits in between cover their landing
+        // (W >= 128); the narrow test nets drain explicitly.
+        // Narrower nets (short layers: the drain is cheap, the extra DMA instructions are not: measured 0.75 vs 0.83 ms on
+        // the 4x128 net) read them with ordinary loads at the point of use.
+        constexpr bool MASK_DMA = W >= 256;
+        const unsigned mlds = ring.lds_base + SM::oMask + wave * (3 * MW * 256);
+        auto mask_issue = [&](int slot, int buf) {
+            if (MASK_DMA) {
 #pragma unroll
-            for (int i = 0; i < MW; ++i) mk[i] = mask_lane[(size_t)slot * a.mask_slot_words + i];
+                for (int i = 0; i < MW; ++i) mcn16_dma4(mask_lane + (size_t)slot * a.mask_slot_words + i, mlds + (buf * MW + i) * 256);
+            }
         };
+        auto mask_read = [&](unsigned (&mk)[MW], int buf, int slot) {
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                if (MASK_DMA) mk[i] = *reinterpret_cast<const unsigned*>(smem + SM::oMask + wave * (3 * MW * 256) + (buf * MW + i) * 256 + lane * 4);
+                else mk[i] = mask_lane[(size_t)slot * a.mask_slot_words + i];
+            }
+        };
+        auto buf_of = [&](int slot) { return (D + 1 - slot) % 3; };
+        mask_issue(D, 0); mask_issue(D + 1, 1); mask_issue(D - 1, 2);
         // ---- per-sample prologue (lane-local): sigmoid and SH backward
         int ray, j;
         if (a.idx) { const int2 rj = a.idx[gc]; ray = rj.x; j = rj.y; }
         else { ray = (int)(gc / a.S); j = (int)(gc - (long long)ray * a.S); }
         unsigned mk_s[MW], mk_c[MW], mk_t[MW];
-        load_mask(mk_s, D); load_mask(mk_c, D + 1); load_mask(mk_t, D - 1);
         float zv = a.zgrid[j];
         if (a.jitter) zv = __fadd_rn(zv, a.jitter[ray]);
         const size_t addr = (size_t)ray * a.S + j;
@@ -173,10 +194,12 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
             }
         {
             char* e = reinterpret_cast<char*>(a.dsh_ws) + (size_t)tile * 2 * 1024 + lane * 16;
-            __builtin_nontemporal_store(dshf[0], reinterpret_cast<u32x4_t*>(e));
-            __builtin_nontemporal_store(dshf[1], reinterpret_cast<u32x4_t*>(e + 1024));
+            mcn16_ws_store(dshf[0], reinterpret_cast<u32x4_t*>(e));
+            mcn16_ws_store(dshf[1], reinterpret_cast<u32x4_t*>(e + 1024));
         }
 
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the prologue's loads and the first three mask buffers have landed
+        mask_read(mk_s, 0, D);
         u32x4_t xa[KS], xb[KS];
         f32x16 denc[2];
         u32x4_t dencp[4];            // the skip layer's share of the encoded-input gradient, parked in 16 bit until layer 0
@@ -193,25 +216,26 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
                 const int i = 4 * (s & 1) + d;
                 xa[s][d] = mcn16_pkmul(T::pack(v0, v1), (mk_s[t >> 1] >> (8 * (t & 1) + 7 - i)) & 0x00010001u);
             }
-            __builtin_nontemporal_store(xa[s], reinterpret_cast<u32x4_t*>(dy_lane + (size_t)D * a.slot_bytes + s * 1024));
+            mcn16_ws_store(xa[s], reinterpret_cast<u32x4_t*>(dy_lane + (size_t)D * a.slot_bytes + s * 1024));
         }
         // ---- sigma.0^T (partial, 16 bit) ; sh.2^T -> dY of sh.0 ; sh.0^T + partial -> dY_{D-1}
+        if (D >= 2) mask_issue(D - 2, buf_of(D - 2));          // buffer 0 is free (the sigma path is done)
         mcn16_bwd_seg<W, BF, KS, NT, 0>(ring, smem, lane, xa, xb, mk_s, denc, nullptr);
+        mask_read(mk_c, 1, D + 1);
         {
             u32x4_t dsh_in[KS];
             dsh_in[0] = dshf[0]; dsh_in[1] = dshf[1];
             mcn16_bwd_seg<W, BF, 2, NT, 1>(ring, smem, lane, dsh_in, xa, mk_c, denc, dy_lane + (size_t)(D + 1) * a.slot_bytes);
         }
-        unsigned mk_n[MW];                                     // masks are fetched one layer ahead of their use
-        if (D >= 2) load_mask(mk_n, D - 2);
+        if (D >= 3) mask_issue(D - 3, buf_of(D - 3));          // buffer 1 is free (sh.2^T is done)
+        mask_read(mk_t, 2, D - 1);
         mcn16_bwd_seg<W, BF, KS, NT, 2>(ring, smem, lane, xa, xb, mk_t, denc, dy_lane + (size_t)(D - 1) * a.slot_bytes);
         // ---- trunk, last layer to first: xb = dY_l
         for (int l = D - 1; l >= 1; --l) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) xa[s] = xb[s];
-#pragma unroll
-            for (int i = 0; i < MW; ++i) mk_t[i] = mk_n[i];
-            if (l >= 2) load_mask(mk_n, l - 2);
+            if (l >= 3) mask_issue(l - 3, buf_of(l - 3));      // the buffer of slot l (previous segment) is free
+            mask_read(mk_t, buf_of(l - 1), l - 1);
             if (l == skip) mcn16_bwd_seg<W, BF, KS, 2, 0, 4>(ring, smem, lane, xa, dencp, mk_t, denc, nullptr);
             mcn16_bwd_seg<W, BF, KS, NT, 1>(ring, smem, lane, xa, xb, mk_t, denc, dy_lane + (size_t)(l - 1) * a.slot_bytes);
         }

@@ -112,8 +112,8 @@ __device__ __forceinline__ void mcn16_layer(Mcn16Ring& ring, char* smem, int lan
                 if (SAVE) mw[t >> 1] |= mb << (8 * (t & 1));
             }
         } else if (SAVE) {
-            if (i == 8) __builtin_nontemporal_store(o0, reinterpret_cast<u32x4_t*>(save_lane + (2 * t) * 1024));
-            else __builtin_nontemporal_store(o1, reinterpret_cast<u32x4_t*>(save_lane + (2 * t + 1) * 1024));
+            if (i == 8) mcn16_ws_store(o0, reinterpret_cast<u32x4_t*>(save_lane + (2 * t) * 1024));
+            else mcn16_ws_store(o1, reinterpret_cast<u32x4_t*>(save_lane + (2 * t + 1) * 1024));
         }
     };
     cur.cur = ring.next_off;
@@ -145,7 +145,7 @@ __device__ __forceinline__ void mcn16_layer(Mcn16Ring& ring, char* smem, int lan
     for (int i = 0; i < NSL; ++i) epi_slice(acc[(NT - 1) & 1], NT - 1, i);
     if (SAVE) {
 #pragma unroll
-        for (int i = 0; i < MW; ++i) __builtin_nontemporal_store(mw[i], mask_lane + i);
+        for (int i = 0; i < MW; ++i) mcn16_ws_store(mw[i], mask_lane + i);
     }
 }
 
@@ -204,12 +204,17 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
         const int addr = ray * a.S + j;
         u32x4_t encf[MCN16_ENCKS];
         mcn16_encode<BF>(p, bw, h, encf);
-        char* act_lane = SAVE ? reinterpret_cast<char*>(a.act_ws) + (size_t)tile * KS * 1024 + lane * 16 : nullptr;
-        unsigned* mask_lane = SAVE ? a.mask_ws + ((size_t)tile * 64 + lane) * MW : nullptr;
+#ifdef ABL16_NOHBM      // (timing-only ablation: every workgroup writes the same few tiles = the stores issue but stay in cache)
+        const long long wtile = tile & 63;
+#else
+        const long long wtile = tile;
+#endif
+        char* act_lane = SAVE ? reinterpret_cast<char*>(a.act_ws) + (size_t)wtile * KS * 1024 + lane * 16 : nullptr;
+        unsigned* mask_lane = SAVE ? a.mask_ws + ((size_t)wtile * 64 + lane) * MW : nullptr;
         if (SAVE) {
-            char* e = reinterpret_cast<char*>(a.enc_ws) + (size_t)tile * MCN16_ENCKS * 1024 + lane * 16;
+            char* e = reinterpret_cast<char*>(a.enc_ws) + (size_t)wtile * MCN16_ENCKS * 1024 + lane * 16;
 #pragma unroll
-            for (int s = 0; s < MCN16_ENCKS; ++s) __builtin_nontemporal_store(encf[s], reinterpret_cast<u32x4_t*>(e + s * 1024));
+            for (int s = 0; s < MCN16_ENCKS; ++s) mcn16_ws_store(encf[s], reinterpret_cast<u32x4_t*>(e + s * 1024));
         }
 
         u32x4_t xa[KS], xb[KS];
@@ -251,8 +256,8 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
             u32x4_t s0, s1;
 #pragma unroll
             for (int d = 0; d < 4; ++d) { s0[d] = T::pack(acc[2 * d], acc[2 * d + 1]); s1[d] = T::pack(acc[8 + 2 * d], acc[8 + 2 * d + 1]); }
-            __builtin_nontemporal_store(s0, reinterpret_cast<u32x4_t*>(e));
-            __builtin_nontemporal_store(s1, reinterpret_cast<u32x4_t*>(e + 1024));
+            mcn16_ws_store(s0, reinterpret_cast<u32x4_t*>(e));
+            mcn16_ws_store(s1, reinterpret_cast<u32x4_t*>(e + 1024));
         }
         // ---- per-sample epilogue: sigma, SH colour (model/net_utils.py:154-169), sigmoid.  Register 4q + e of this lane
         //      is SH row n = 8q + 4h + e = 9 c + i (colour c, basis i); the two lane halves hold complementary rows.

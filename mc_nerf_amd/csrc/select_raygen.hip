@@ -98,6 +98,104 @@ hipError_t mcn_launch_cap_gather(const int2* idx_in, const long long* perm, int 
     return hipGetLastError();
 }
 
+// ---- The random cap of model/mc_nerf.py:630-632 without a host round trip.  The reference keeps idx[randperm(K)[:keep]]
+// when K > keep: a uniformly random subset of size `keep` (the order of the list never reaches a result).  Here every
+// entry i < K gets a 32-bit key hash(seed, i) and the `keep` smallest keys are kept: two 65536-bin histogram passes find
+// the exact threshold key, one pass appends the kept entries (wave-aggregated atomics).  K <= keep keeps everything.
+// ws (uint32): [0 .. 65535] histogram of the high 16 key bits, [65536 .. 131071] histogram of the low 16 bits inside the
+// boundary bin, [131072] boundary bin (0x10000 = keep all), [131073] entries below it, [131074] threshold key,
+// [131075] ties to take at the threshold, [131076] tie counter, [131077] output cursor.
+__device__ __forceinline__ unsigned cap_key(unsigned seed, unsigned i) {
+    unsigned x = i * 0x9E3779B9u + seed;          // murmur3 finaliser: every output bit depends on every input bit
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void cap_hist_hi_kernel(const int* count, int max_rows, int keep, const unsigned* seed, unsigned* ws) {
+    const int K = min(*count, max_rows);
+    if (K <= keep) return;
+    const unsigned sd = *seed;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) atomicAdd(&ws[cap_key(sd, i) >> 16], 1u);
+}
+// one workgroup: first bin whose inclusive prefix reaches `target`; writes (bin, prefix before it)
+__device__ void cap_find(const unsigned* hist, unsigned target, unsigned* out_bin, unsigned* out_below) {
+    __shared__ unsigned part[1024];
+    const int tid = threadIdx.x;
+    unsigned s = 0;
+    for (int b = 0; b < 64; ++b) s += hist[tid * 64 + b];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned cum = 0;
+        int t = 0;
+        while (t < 1024 && cum + part[t] < target) { cum += part[t]; ++t; }
+        int b = t * 64;
+        if (t < 1024) { while (cum + hist[b] < target) { cum += hist[b]; ++b; } }
+        *out_bin = (unsigned)b; *out_below = cum;
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(1024) void cap_find_hi_kernel(const int* count, int max_rows, int keep, unsigned* ws) {
+    const int K = min(*count, max_rows);
+    if (K <= keep) { if (threadIdx.x == 0) { ws[131072] = 0x10000u; ws[131074] = 0xFFFFFFFFu; ws[131075] = 0xFFFFFFFFu; } return; }
+    cap_find(ws, (unsigned)keep, &ws[131072], &ws[131073]);
+}
+__global__ __launch_bounds__(256) void cap_hist_lo_kernel(const int* count, int max_rows, int keep, const unsigned* seed, unsigned* ws) {
+    const int K = min(*count, max_rows);
+    if (K <= keep) return;
+    const unsigned sd = *seed, bin = ws[131072];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) {
+        const unsigned k = cap_key(sd, i);
+        if ((k >> 16) == bin) atomicAdd(&ws[65536 + (k & 0xFFFFu)], 1u);
+    }
+}
+__global__ __launch_bounds__(1024) void cap_find_lo_kernel(const int* count, int max_rows, int keep, unsigned* ws) {
+    const int K = min(*count, max_rows);
+    if (K <= keep) return;
+    __shared__ unsigned lo, below;
+    cap_find(ws + 65536, (unsigned)keep - ws[131073], &lo, &below);
+    if (threadIdx.x == 0) {
+        ws[131074] = (ws[131072] << 16) | lo;                        // threshold key: all smaller keys are kept
+        ws[131075] = (unsigned)keep - ws[131073] - below;            // ... and this many entries with exactly that key
+    }
+}
+__global__ __launch_bounds__(256) void cap_write_kernel(const int2* idx_in, const int* count, int max_rows, int keep, const unsigned* seed,
+                                                        unsigned* ws, int2* idx_out, int* count_out) {
+    const int K = min(*count, max_rows);
+    const unsigned sd = *seed, thr = ws[131074], ties = ws[131075];
+    const int lane = threadIdx.x & 63;
+    const int rounds = (K + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
+    for (int r = 0; r < rounds; ++r) {
+        const int i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;       // consecutive entries stay together
+        bool sel = false;
+        if (i < K) {
+            if (K <= keep) sel = true;
+            else {
+                const unsigned k = cap_key(sd, (unsigned)i);
+                sel = k < thr || (k == thr && atomicAdd(&ws[131076], 1u) < ties);
+            }
+        }
+        const unsigned long long m = __ballot(sel);
+        unsigned base = 0;
+        if (lane == 0 && m) base = atomicAdd(&ws[131077], (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (sel) idx_out[base + __popcll(m & ((1ull << lane) - 1ull))] = idx_in[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = min(K, keep);
+}
+hipError_t mcn_launch_cap_random(const int2* idx_in, const int* count, int max_rows, int keep, const unsigned* seed, unsigned* ws,
+                                 int2* idx_out, int* count_out, hipStream_t st) {
+    if (max_rows <= 0 || keep <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(ws, 0, MCN_CAP_WS * sizeof(unsigned), st);
+    if (e != hipSuccess) return e;
+    const int blocks = min((max_rows + 255) / 256, 2048);
+    hipLaunchKernelGGL(cap_hist_hi_kernel, dim3(blocks), dim3(256), 0, st, count, max_rows, keep, seed, ws);
+    hipLaunchKernelGGL(cap_find_hi_kernel, dim3(1), dim3(1024), 0, st, count, max_rows, keep, ws);
+    hipLaunchKernelGGL(cap_hist_lo_kernel, dim3(blocks), dim3(256), 0, st, count, max_rows, keep, seed, ws);
+    hipLaunchKernelGGL(cap_find_lo_kernel, dim3(1), dim3(1024), 0, st, count, max_rows, keep, ws);
+    hipLaunchKernelGGL(cap_write_kernel, dim3(blocks), dim3(256), 0, st, idx_in, count, max_rows, keep, seed, ws, idx_out, count_out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ ray generation
 // d = normalize(R^T K^-1 [u+.5, v+.5, 1]^T), o = -R^T t, following the reference's op order
 // (pix @ K^-T, lift, @ pose_inv^T, minus origin, normalise) so results agree to ~1e-7.

@@ -43,18 +43,26 @@ def _cap_needed(st: RenderSettings) -> bool:
 
 
 def select_and_cap(st: RenderSettings, w_sel, wmax, n_rays, cap_perm, train: bool):
-    """Device-side selection; applies the random cap in training.  Returns idx, count, out_f, max_rows."""
+    """Device-side selection; applies the random cap in training.  Returns idx, count, out_f, max_rows.
+    No host synchronisation: the cap's random subset is drawn on the device (ops.cap_random) with a seed word taken
+    from torch's device generator.  Only a caller-supplied permutation (`cap_perm`, the parity-test input that replays
+    the reference's CPU randperm, :631) goes through the host: its length IS the host-side count."""
     idx, count, out_f = ops.select_fine(w_sel, wmax, st.weight_thresh, st.scale, st.sigma_default)
     max_rows = n_rays * st.samples_f
     if train and _cap_needed(st):
         keep = n_rays * st.max_fine_per_ray
-        k = int(count.item())                      # the only host sync of the train path; cfg 2 never takes it
-        if k > keep:
-            if cap_perm is None:
-                cap_perm = torch.randperm(k)[:keep]        # CPU generator, as the reference (:631)
-            perm = cap_perm[:keep].to(device=idx.device, dtype=torch.int64).contiguous()
-            idx, count = ops.cap_gather(idx, perm, keep)
-        max_rows = min(max_rows, max(k, 1)) if k <= keep else keep
+        if cap_perm is not None:
+            k = int(count.item())                  # (test path only)
+            if k > keep:
+                perm = cap_perm[:keep].to(device=idx.device, dtype=torch.int64).contiguous()
+                idx, count = ops.cap_gather(idx, perm, keep)
+                max_rows = keep
+            else:
+                max_rows = min(max_rows, max(k, 1))
+        else:
+            seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int32, device=idx.device)
+            idx, count = ops.cap_random(idx, count, max_rows, keep, seed)
+            max_rows = keep
     return idx, count, out_f, max_rows
 
 

@@ -285,6 +285,17 @@ def cap_gather(idx: Tensor, perm: Tensor, keep: int):
     return idx2, count
 
 
+def cap_random(idx: Tensor, count: Tensor, max_rows: int, keep: int, seed: Tensor):
+    """Device-side random cap (model/mc_nerf.py:630-632 without the host sync): -> idx2 [keep,2], count2 = min(count, keep)."""
+    dev = idx.device
+    idx2 = torch.empty(keep, 2, dtype=torch.int32, device=dev)
+    count2 = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(_lib.lib().mcnerf_cap_ws_words()), dtype=torch.int32, device=dev)
+    _lib.call("mcnerf_cap_random", _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), int(keep), _p(seed, torch.int32),
+              _p(ws, torch.int32), _p(idx2, torch.int32), _p(count2, torch.int32), _stream())
+    return idx2, count2
+
+
 def camera_fwd(wpose: Tensor, wpose_intr: Tensor, wfx: Tensor, wfy: Tensor, wux: Tensor, wuy: Tensor, H: int, W: int):
     """-> K [C,3,3], Kinv [C,3,3], pose [C,3,4], calib_pose [C,3,4]"""
     C, dev = wpose.shape[0], wpose.device

@@ -481,7 +481,8 @@ def test_full_size_precision_modes_agree(gpu_device):
 def test_full_size_cap_path(gpu_device, precision):
     """BASELINE configs[4]-like sampling (64 coarse + 256 fine grid, scale 4) on the full-size nets: more than 128 fine
     samples per ray get selected at random init, so the training cap (model/mc_nerf.py:630-632) binds -- exactly
-    N * 128 samples are evaluated, through the host-synchronised permutation path, and the step stays finite."""
+    N * 128 samples are evaluated, the random subset is drawn on the device WITHOUT any host synchronisation, and the
+    step stays finite."""
     dev = gpu_device
     from mc_nerf_amd.model import NeRF_Model, MC_NeRF_Loss
     cfg = O.RenderCfg(samples=64, scale=4, coarse=O.NetCfg(4, 128, (2,)), fine=O.NetCfg(8, 256, (4,)))
@@ -490,8 +491,16 @@ def test_full_size_cap_path(gpu_device, precision):
     m.nerf_fine.load_state_dict(O.init_params(cfg.fine, 4))
     n = 4096
     d, o, kw = _full_size_inputs(n, cfg, dev, seed=29)
-    torch.manual_seed(0)                                       # the cap permutation comes from the CPU generator (:631)
-    c, f = m.render_rays_train(d, o, 0, 0.5, **kw)
+    torch.manual_seed(0)
+    real_item = torch.Tensor.item
+
+    def no_item(self):                                         # any .item() inside the render would be a host sync
+        raise AssertionError("host synchronisation (.item()) on the train path")
+    torch.Tensor.item = no_item
+    try:
+        c, f = m.render_rays_train(d, o, 0, 0.5, **kw)
+    finally:
+        torch.Tensor.item = real_item
     k = int(m.last_selection[1].item())
     assert k == n * 128, k
     idx = m.last_selection[0][:k].long()

@@ -380,3 +380,41 @@ def test_gather_gt_from_device_resident_images(gpu_device):
         assert maxerr(got, ref[pix]) == 0.0
         assert maxerr(ds.full_image(2), (u8[2].float() / 255.0)[:, :3] * ((u8[2].float() / 255.0)[:, 3:] if ch == 4 else 1)
                       + ((1 - u8[2].float()[:, 3:] / 255.0) if ch == 4 else 0)) < 1e-7
+
+
+def test_cap_random_device_side(gpu_device):
+    """The device-side random cap (model/mc_nerf.py:630-632 without the host sync): exactly `keep` distinct entries of the
+    first *count, every entry equally likely, everything copied when the cap does not bind."""
+    ops = _ops()
+    dev = gpu_device
+    K, cap, keep = 50000, 70000, 20000
+    idx = torch.stack([torch.arange(cap, dtype=torch.int32) // 97, torch.arange(cap, dtype=torch.int32) % 97], 1).to(dev)
+    count = torch.tensor([K], dtype=torch.int32, device=dev)
+    hits = torch.zeros(K, device=dev)
+    trials = 64
+    for t in range(trials):
+        seed = torch.tensor([1234567 * t + 11], dtype=torch.int32, device=dev)
+        idx2, c2 = ops.cap_random(idx, count, cap, keep, seed)
+        assert int(c2.item()) == keep
+        flat = idx2[:, 0].long() * 97 + idx2[:, 1].long()
+        assert int(flat.max()) < K and torch.unique(flat).numel() == keep            # a subset of the valid entries, no duplicates
+        hits[flat] += 1
+    # every entry is kept with probability keep / K = 0.4: the per-entry hit count is Binomial(64, 0.4)
+    mean = float(hits.mean()) / trials
+    assert abs(mean - keep / K) < 1e-6
+    assert float(hits.max()) <= 48 and float(hits.min()) >= 6                        # ~ +-5.7 sigma
+    halves = hits[: K // 2].mean() / hits[K // 2:].mean()
+    assert abs(float(halves) - 1.0) < 0.01                                           # no positional bias
+    # same seed -> same subset (as a set)
+    seed = torch.tensor([42], dtype=torch.int32, device=dev)
+    a, _ = ops.cap_random(idx, count, cap, keep, seed)
+    b, _ = ops.cap_random(idx, count, cap, keep, seed)
+    sa = torch.sort(a[:, 0].long() * 97 + a[:, 1].long()).values
+    sb = torch.sort(b[:, 0].long() * 97 + b[:, 1].long()).values
+    assert torch.equal(sa, sb)
+    # cap not binding: the first *count entries, all of them
+    small = torch.tensor([1500], dtype=torch.int32, device=dev)
+    idx3, c3 = ops.cap_random(idx, small, cap, keep, seed)
+    assert int(c3.item()) == 1500
+    got = torch.sort(idx3[:1500, 0].long() * 97 + idx3[:1500, 1].long()).values
+    assert torch.equal(got, torch.arange(1500, device=dev))
