@@ -319,7 +319,7 @@ def _golden_model(g, dev, precision):
 
 
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
-@pytest.mark.parametrize("name", ["g7_train_s64x2_small", "g7_train_s32x5_small_barf", "g7_train_s64x2_full"])
+@pytest.mark.parametrize("name", ["g7_train_s64x2_small", "g7_train_s32x5_small_barf", "g7_train_s32x5_cap", "g7_train_s64x2_full"])
 def test_render_train_16bit_vs_reference_golden(gpu_device, name, precision):
     from conftest import load_golden, t
     from mc_nerf_amd.model import MC_NeRF_Loss
@@ -328,8 +328,9 @@ def test_render_train_16bit_vs_reference_golden(gpu_device, name, precision):
     m, cfg = _golden_model(g, dev, precision)
     d = t(g["rays_d"]).to(dev).requires_grad_(True)
     o = t(g["rays_o"]).to(dev).requires_grad_(True)
+    kw = {"cap_perm": t(g["cap_perm"])} if "cap_perm" in g else {}       # the reference's captured cap permutation (:631)
     rgb_c, rgb_f = m.render_rays_train(d, o, 0, float(g["step_r"]), jitter=t(g["jitter"]).to(dev), eps_c=t(g["eps_c"]).to(dev),
-                                       eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
+                                       eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev), **kw)
     loss = MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([rgb_c, rgb_f, t(g["gt"]).to(dev)])
     loss.backward()
     e_c = float((rgb_c.detach().cpu() - t(g["rgb_c"])).abs().max())
