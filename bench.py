@@ -399,8 +399,13 @@ def run_render(args, rank, world, dev):
     from mc_nerf_amd.model import MC_Model
     torch.manual_seed(42 + rank)
     H = W = 800
-    sp = S.make_sys_param(dev, samples=64, scale=2, batch=args.rays, H=H, W=W, barf_mask=False, precision=args.precision, mode=1)
-    model = MC_Model(sp).to(dev).eval()
+    import tempfile
+    kw = dict(samples=64, scale=2, batch=args.rays, H=H, W=W, barf_mask=False, precision=args.precision)
+    tmp = tempfile.mkdtemp(prefix=f"mcnerf_bench_r{rank}_")
+    trained = MC_Model(S.make_sys_param(dev, root_weight=tmp, **kw)).to(dev)        # random-init weights, written in the
+    ckpt = trained.nerf.save_model(trained, 0)                                      # reference's checkpoint format ...
+    del trained
+    model = MC_Model(S.make_sys_param(dev, mode=1, demo_ckpt=ckpt, **kw)).to(dev).eval()    # ... and loaded the way the demo does
     cams = D.shard_cameras(model.train_numb, 0, rank, world, seed=42)
     n_img = max(1, args.steps)
 

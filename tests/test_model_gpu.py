@@ -224,6 +224,52 @@ def test_mc_model_demo_call(gpu_device):
     assert rgb.device.type == "cpu" and bool(torch.isfinite(rgb).all()) and float(opacity.min()) >= 0.0
 
 
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("f16", 2e-3)])
+def test_demo_mode_from_reference_format_checkpoint_matches_oracle(gpu_device, tmp_path, precision, tol):
+    """a reference-format checkpoint ({'model_nerf': MC_Model.state_dict()}, model/mc_nerf.py:738-752) is
+    written by save_model, a fresh MC_Model is built in demo mode from `demo_ckpt` (:577-584, 815-837) and renders a whole
+    (small) image through model(img_idx) in `batch` chunks (:106-122); rgb / depth / opacity are compared with the CPU
+    oracle chunk by chunk on the same rays and the same N(0,1) draws (the model draws them from torch's device generator
+    in the reference's order: eps_c, eps_sel, eps_f per chunk)."""
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd.model import MC_Model
+    dev = gpu_device
+    H, W, B, cam = 18, 22, 150, 7
+    kw = dict(samples=32, scale=2, batch=B, H=H, W=W, coarse=(4, 32, [2]), fine=(8, 64, [4]), root_weight=str(tmp_path),
+              precision=precision)
+    torch.manual_seed(3)
+    trained = MC_Model(S.make_sys_param(dev, **kw)).to(dev)
+    with torch.no_grad():                                   # make the density non-trivial (random init renders almost empty space)
+        trained.nerf.nerf_coarse.sigma[2].bias.add_(1.5)
+        trained.nerf.nerf_fine.sigma[2].bias.add_(1.5)
+    path = trained.nerf.save_model(trained, epoch=1)
+    torch.manual_seed(99)                                   # different init: the weights must come from the checkpoint
+    demo = MC_Model(S.make_sys_param(dev, mode=1, demo_ckpt=path, **kw)).to(dev)
+    torch.manual_seed(1234)
+    rgb, depth, opacity = demo(torch.tensor([cam]))
+    assert rgb.device.type == "cpu" and rgb.shape == (H * W, 3) and depth.shape == (H * W, 1) and opacity.shape == (H * W, 1)
+    # ---- oracle on the same rays / draws
+    cfg = O.RenderCfg(samples=32, scale=2, coarse=O.NetCfg(4, 32, (2,)), fine=O.NetCfg(8, 64, (4,)))
+    sd = torch.load(path, map_location="cpu")["model_nerf"]
+    pc = {k[len("nerf.nerf_coarse."):]: v for k, v in sd.items() if k.startswith("nerf.nerf_coarse.")}
+    pf = {k[len("nerf.nerf_fine."):]: v for k, v in sd.items() if k.startswith("nerf.nerf_fine.")}
+    sp = demo.sys_param
+    d_all, o_all = O.get_rays(sp["test_pose"][cam], sp["intr_mat_inv"][1][cam], H, W)
+    torch.manual_seed(1234)
+    worst = [0.0, 0.0, 0.0]
+    for i in range(0, H * W, B):
+        n = min(B, H * W - i)
+        eps = [torch.randn(n, s, device=dev).cpu() for s in (32, 32, 64)]      # the model's draws, replayed
+        with torch.no_grad():
+            ref = O.render_rays_test(pc, pf, cfg, d_all[i:i + n], o_all[i:i + n], eps[0], eps[1], eps[2])
+        for j, (a, b) in enumerate(((rgb[i:i + n], ref["rgb"]), (depth[i:i + n], ref["depth"].reshape(-1, 1)),
+                                    (opacity[i:i + n], ref["opacity"].reshape(-1, 1)))):
+            worst[j] = max(worst[j], float((a - b).abs().max()))
+    print(f"[{precision}] demo render {H}x{W} in chunks of {B}: max|rgb| {worst[0]:.1e} max|depth| {worst[1]:.1e} max|opacity| {worst[2]:.1e}")
+    assert worst[0] < tol and worst[2] < tol and worst[1] < 5 * tol
+    assert float(opacity.max()) > 0.5                       # the scene is not empty: the comparison means something
+
+
 def test_mc_model_step_matches_reference_golden(gpu_device, monkeypatch):
     """MC_Model.forward (GLOBAL_OPTIM) + loss + backward against the values captured from the ACTUAL reference
     (g11): same parameters, same pixel subset, same jitter / noise draws."""
