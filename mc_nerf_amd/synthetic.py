@@ -54,6 +54,120 @@ def ball_cameras(seed: int = 0, radius: float = 3.0, H: int = 800, W: int = 800)
             np.array(fovs))
 
 
+def _pose_from_blender(loc, euler_xz, fov, H, W):
+    """Blender camera (location, Euler XYZ = (rx, 0, rz), FOV in degrees) -> the reference's world->cam [R|t] and K
+    (data/data_read.py:141-152 fov -> K, :246-257 flip y,z and invert)."""
+    rx, rz = euler_xz
+    R_c2w = _rot_z(rz) @ _rot_x(rx)
+    R_w2c = (R_c2w @ np.diag([1.0, -1.0, -1.0])).T
+    t_w2c = -R_w2c @ np.asarray(loc, dtype=np.float64).reshape(3, 1)
+    f = math.radians(fov)
+    K = np.array([[(W / 2) / math.tan(f / 2), 0, W / 2], [0, (H / 2) / math.tan(f / 2), H / 2], [0, 0, 1]])
+    return np.concatenate([R_w2c, t_w2c], axis=1), K
+
+
+def _rig_tensors(locs, eulers, fovs, H, W):
+    P, Ks = zip(*[_pose_from_blender(l, e, f, H, W) for l, e, f in zip(locs, eulers, fovs)])
+    return torch.tensor(np.stack(P), dtype=torch.float32), torch.tensor(np.stack(Ks), dtype=torch.float32), np.array(fovs)
+
+
+def _gen_rot_x(deg):        # the generators' row-vector Rot_X (note the sign flip inside, Array.py:129-134)
+    r = -math.radians(deg)
+    return np.array([[1, 0, 0], [0, math.cos(r), math.sin(r)], [0, -math.sin(r), math.cos(r)]])
+
+
+def _gen_rot_z(deg):        # Array.py:122-127
+    r = math.radians(deg)
+    return np.array([[math.cos(r), math.sin(r), 0], [-math.sin(r), math.cos(r), 0], [0, 0, 1]])
+
+
+def array_cameras(seed: int = 0, H: int = 800, W: int = 800):
+    """Array_* rig (BASELINE configs[2]; synthetic_dataset_code/Array.py:18-35, 176-191, 248-263): a 10 x 10 planar grid of
+    3 x 3 units at distance 4, tilted 45 degrees about z after a 90-degree turn about x, every camera aimed at the origin
+    by the generator's look-at (pitch from atan(z / r_xy), yaw from the xy direction); integer FOVs in [40, 80] from
+    random.seed(seed).  -> pose [100,3,4], K [100,3,3], fov_deg [100]"""
+    rnd = random.Random(seed)
+    fovs = [rnd.randint(40, 80) for _ in range(100)]
+    xs, ys = np.linspace(-1.5, 1.5, 10), np.linspace(-1.5, 1.5, 10)
+    X, Y = np.meshgrid(xs, ys)
+    cord = np.stack([X, Y, -4.0 * np.ones_like(X)], -1).reshape(-1, 3) @ _gen_rot_x(90) @ _gen_rot_z(45)
+    eulers = []
+    for loc in cord:
+        r = np.linalg.norm(loc[:2])
+        phi = math.atan(loc[2] / r)
+        v = loc[:2] / r
+        cos_t, sin_t = float(np.dot(v, [0.0, -1.0])), float(np.cross(v, [0.0, -1.0]))
+        theta = 2 * math.pi - math.acos(max(-1.0, min(1.0, cos_t))) if sin_t > 0 else math.acos(max(-1.0, min(1.0, cos_t)))
+        eulers.append((math.radians(90) - phi, theta))
+    return _rig_tensors(cord, eulers, fovs, H, W)
+
+
+def halfball_cameras(seed: int = 0, H: int = 800, W: int = 800, radius: float = 3.0):
+    """HalfBall_* rig (BASELINE configs[3]; synthetic_dataset_code/HalfBall.py:14-26, 162-178): 100 cameras on the upper
+    half sphere of radius 3 at integer angles theta in [0, 360], phi in [0, 90] from random.seed(seed) (FOVs first, as
+    the generator draws them), Euler XYZ (90 deg - phi, 0, theta)."""
+    rnd = random.Random(seed)
+    fovs = [rnd.randint(40, 80) for _ in range(100)]
+    start = np.array([0.0, -radius, 0.0])
+    locs, eulers = [], []
+    for _ in range(100):
+        theta, phi = rnd.randint(0, 360), rnd.randint(0, 90)
+        locs.append(start @ _gen_rot_x(phi) @ _gen_rot_z(theta))
+        eulers.append((math.radians(90) - math.radians(phi), math.radians(theta)))
+    return _rig_tensors(locs, eulers, fovs, H, W)
+
+
+def room_cameras(seed: int = 0, H: int = 800, W: int = 800):
+    """Room_* rig (BASELINE configs[4]; synthetic_dataset_code/Room.py:18-34, 171-180, 197-310): 88 inward-looking cameras
+    on the walls of a 6 x 4 x 3 room -- 24 on the floor edge and 24 on the ceiling edge (every 15 degrees, where the ray
+    from the centre meets the rectangle) and 5 rings of 8 (wall centres and corners) in between; pitch atan(z / r_xy)
+    towards the floor centre, yaw stepping with the position."""
+    rnd = random.Random(seed)
+    fovs = [rnd.randint(40, 80) for _ in range(88)]
+    rx, ry, rz, step, rounds = 6.0, 4.0, 3.0, 15, 7
+    n_loc = 180 // step
+    mid = []
+    for i in range(1, rounds - 1):
+        z = rz / rounds * i
+        mid += [(rx / 2, 0, z), (rx / 2, ry / 2, z), (0, ry / 2, z), (-rx / 2, ry / 2, z), (-rx / 2, 0, z), (-rx / 2, -ry / 2, z),
+                (0, -ry / 2, z), (rx / 2, -ry / 2, z)]
+    e1, e2 = [], []
+    for i in range(n_loc):
+        ang = step * i
+        if ang == 90:
+            p1, p2 = (0.0, ry / 2), (0.0, -ry / 2)
+        elif ang == 0:
+            p1, p2 = (rx / 2, 0.0), (-rx / 2, 0.0)
+        else:
+            t = math.tan(math.radians(ang))
+            x_abs = ry / (2 * t)
+            sym = 1.0 if x_abs > 0 else -1.0
+            y_abs = sym * t * rx / 2
+            if abs(x_abs) >= rx / 2:
+                p1, p2 = (rx / 2 * sym, y_abs), (-rx / 2 * sym, -y_abs)
+            else:
+                p1, p2 = (x_abs, ry / 2), (-x_abs, -ry / 2)
+        e1.append(p1)
+        e2.append(p2)
+    edge = e1 + e2
+    locs = [(x, y, 0.0) for x, y in edge] + mid + [(x, y, rz) for x, y in edge]
+    theta_t = math.atan(ry / rx)
+    ring_yaw = [math.radians(90), math.radians(90) + theta_t, math.radians(180), math.radians(270) - theta_t, math.radians(270),
+                math.radians(270) + theta_t, math.radians(360), math.radians(450) - theta_t]
+    eulers = []
+    for k, loc in enumerate(locs):
+        pitch = -math.atan(loc[2] / math.hypot(loc[0], loc[1]))
+        if k < 24 or k >= 64:                      # floor / ceiling edge: yaw = 90 deg + 15 deg per position
+            yaw = math.radians(90) + math.radians(step) * (k if k < 24 else k - 64)
+        else:
+            yaw = ring_yaw[(k - 24) % 8]
+        eulers.append((math.radians(90) + pitch, yaw))
+    return _rig_tensors(locs, eulers, fovs, H, W)
+
+
+RIGS = {"ball": None, "array": array_cameras, "halfball": halfball_cameras, "room": room_cameras}
+
+
 def se3_log(pose: torch.Tensor) -> torch.Tensor:
     """[C,3,4] -> [C,6] (w,u) such that the model's se3_to_SE3(wu) reproduces the pose (closed-form A,B,C)."""
     out = []
@@ -94,9 +208,10 @@ def calibration_points(pose: torch.Tensor, K: torch.Tensor, seed: int = 0):
 
 
 def make_sys_param(device, *, samples=64, scale=2, batch=7000, H=800, W=800, coarse=(4, 128, [2]), fine=(8, 256, [4]),
-                   mode=0, barf_mask=False, barf_start=0.3846, barf_end=0.6923, seed=0, n_val_images=1, **extra):
-    """`sys_param` for a Ball_Lego-shaped synthetic scene (the keys listed in SURVEY.md 8b)."""
-    pose, K, _ = ball_cameras(seed, H=H, W=W)
+                   mode=0, barf_mask=False, barf_start=0.3846, barf_end=0.6923, seed=0, n_val_images=1, rig="ball", **extra):
+    """`sys_param` for a synthetic scene on one of the reference's rigs (`rig`: ball | array | halfball | room; the
+    keys listed in SURVEY.md 8b)."""
+    pose, K, _ = ball_cameras(seed, H=H, W=W) if rig == "ball" else RIGS[rig](seed, H=H, W=W)
     C = pose.shape[0]
     Kinv = torch.linalg.inv(K)
     g = torch.Generator().manual_seed(seed + 1)

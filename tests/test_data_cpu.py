@@ -43,3 +43,39 @@ def test_load_blender_split(tmp_path):
         assert np.array_equal(d["images"].images[i].numpy(), img)
     s = DeviceImageSet.synthetic(10, 4, 4, "cpu")
     assert len(s) == 10 and torch.equal(s.images[0], s.images[4]) and not torch.equal(s.images[0], s.images[1])
+
+
+def test_array_halfball_room_rigs_are_sane():
+    """The rigs of BASELINE configs 3-5 (synthetic_dataset_code/Array.py, HalfBall.py, Room.py): camera counts, proper
+    rotations, camera centres where the generators put them, every camera looking towards the scene (the origin lies in
+    front of it, near the optical axis), intrinsics from the integer FOVs, and a model built on each rig."""
+    import math
+    import torch
+    from mc_nerf_amd import synthetic as S
+    for name, n, check_centre in (("array", 100, lambda c: abs(float(c.norm()) - 4.0) < 1.6),
+                                  ("halfball", 100, lambda c: abs(float(c.norm()) - 3.0) < 1e-4 and float(c[2]) >= -1e-5),
+                                  ("room", 88, lambda c: abs(float(c[0])) <= 3.0 + 1e-5 and abs(float(c[1])) <= 2.0 + 1e-5 and -1e-6 <= float(c[2]) <= 3.0 + 1e-5)):
+        pose, K, fov = S.RIGS[name](0, H=800, W=800)
+        assert pose.shape == (n, 3, 4) and K.shape == (n, 3, 3) and len(fov) == n
+        R, t = pose[:, :, :3], pose[:, :, 3]
+        assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(n, 3, 3), atol=1e-5)
+        assert torch.allclose(torch.linalg.det(R), torch.ones(n), atol=1e-5)
+        centres = -(R.transpose(1, 2) @ t.unsqueeze(-1)).squeeze(-1)              # camera centre = -R^T t
+        assert all(check_centre(c) for c in centres), name
+        if name != "halfball":                                                     # (HalfBall draws integer angles with replacement)
+            assert len({tuple(round(float(v), 4) for v in c) for c in centres}) == n
+        cam_pts = (R @ (torch.zeros(3) - centres).unsqueeze(-1)).squeeze(-1)       # the rigs' aim point (origin) in camera coordinates
+        ahead = cam_pts[:, 2] > 0
+        off_axis = torch.rad2deg(torch.atan2(cam_pts[:, :2].norm(dim=1), cam_pts[:, 2].abs()))
+        assert bool(ahead.all()) and float(off_axis.max()) < (1e-3 if name != "room" else 35.0), (name, float(off_axis.max()))
+        if name == "room":                                                         # yaw steps by position, pitch aims at the floor centre
+            assert float(off_axis.median()) < 1.0
+        assert all(40 <= f <= 80 for f in fov)
+        fx = torch.tensor([400.0 / math.tan(math.radians(float(f)) / 2) for f in fov])
+        assert torch.allclose(K[:, 0, 0], fx, rtol=1e-5) and torch.allclose(K[:, 0, 2], torch.full((n,), 400.0))
+        sp = S.make_sys_param("cpu", rig=name, H=8, W=8, batch=16, coarse=(4, 32, [2]), fine=(8, 64, [4]))
+        from mc_nerf_amd.model import MC_Model
+        m = MC_Model(sp)
+        assert m.weights_pose.shape == (n, 6) and m.train_numb == n
+        S.init_cameras_near_gt(m)
+        assert float((m.se3_to_SE3(m.weights_pose) - sp["gt_pose"]).abs().max()) < 5e-3   # se(3) log -> 10-term Taylor exp round trip (rotations near pi are the worst case)
