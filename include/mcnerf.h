@@ -201,17 +201,26 @@ int mcnerf_gather_gt(const uint8_t* image, int channels, const int64_t* pix, int
 
 /* Fused camera parametrisation of all C cameras.
  * Replaces add_weights2intr / add_weights2pose / add_weights2calib_pose / se3_to_SE3 / taylor_A,B,C /
- * inverse_intrinsic (model/mc_nerf.py:171-210, 269-316):
+ * inverse_intrinsic (model/mc_nerf.py:171-210, 269-316) and the calibration reprojection branch get_reproject_pixels /
+ * world2cam / cam2pix (model/mc_nerf.py:147-152, 236-267):
  *   K [C,3,3] = [[|W wfx|,0,|W/2 wux|],[0,|W wfy|,|H/2 wuy|],[0,0,1]], Kinv its analytic inverse,
- *   pose / calib [C,3,4] = se3_to_SE3(wpose / wpose_intr) with the reference's 11-term Taylor series. */
+ *   pose / calib [C,3,4] = se3_to_SE3(wpose / wpose_intr) with the reference's 11-term Taylor series,
+ *   pix_intr [C,P,2] = pixels of wpts_intr [C,P,3] through (K, calib), pix_extr = wpts_extr through (K, pose)
+ *   (each pair may be NULL: branch not evaluated). */
 int mcnerf_camera_fwd(const float* wpose, const float* wpose_intr, const float* wfx, const float* wfy, const float* wux,
-                      const float* wuy, int C, int H, int W, float* K, float* Kinv, float* pose, float* calib, void* stream);
-/* Backward of the above: upstream dK / dKinv [C,3,3], dpose / dcalib [C,3,4] (any may be NULL) ->
- * gradients of the six parameter tensors (WRITTEN, not accumulated). */
+                      const float* wuy, int C, int H, int W, float* K, float* Kinv, float* pose, float* calib,
+                      const float* wpts_intr, const float* wpts_extr, int P, float* pix_intr, float* pix_extr, void* stream);
+/* Backward of the above: upstream dK / dKinv [C,3,3], dpose / dcalib [C,3,4], dpix_intr / dpix_extr [C,P,2] (any may be
+ * NULL) -> gradients of the six parameter tensors (WRITTEN, not accumulated). */
 int mcnerf_camera_bwd(const float* wpose, const float* wpose_intr, const float* wfx, const float* wfy, const float* wux,
                       const float* wuy, int C, int H, int W, const float* dK, const float* dKinv, const float* dpose,
-                      const float* dcalib, float* d_wpose, float* d_wpose_intr, float* d_wfx, float* d_wfy, float* d_wux,
+                      const float* dcalib, const float* wpts_intr, const float* wpts_extr, int P, const float* dpix_intr,
+                      const float* dpix_extr, float* d_wpose, float* d_wpose_intr, float* d_wfx, float* d_wfy, float* d_wux,
                       float* d_wuy, void* stream);
+/* Reprojection loss of n = B*C*P points (model/loss.py:45-58): *loss = mean((pd_x-gt_x)^2)/W^2 + mean((pd_y-gt_y)^2)/H^2;
+ * backward: d_pd [n,2] from the device scalar *dloss. */
+int mcnerf_reproj_loss_fwd(const float* pd, const float* gt, int n, int H, int W, float* loss, void* stream);
+int mcnerf_reproj_loss_bwd(const float* pd, const float* gt, int n, int H, int W, const float* dloss, float* d_pd, void* stream);
 
 /* Fused multi-tensor Rectified-Adam step (one launch for all tensors of a param group).
  * Replaces the per-tensor loop of RAdam.step (model/net_utils.py:38-99).  The arrays of n_tensors device

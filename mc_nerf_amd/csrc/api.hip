@@ -304,20 +304,32 @@ int mcnerf_gather_gt(const uint8_t* image, int channels, const int64_t* pix, int
 }
 
 int mcnerf_camera_fwd(const float* wpose, const float* wpose_intr, const float* wfx, const float* wfy, const float* wux,
-                      const float* wuy, int C, int H, int W, float* K, float* Kinv, float* pose, float* calib, void* stream) {
+                      const float* wuy, int C, int H, int W, float* K, float* Kinv, float* pose, float* calib,
+                      const float* wpts_intr, const float* wpts_extr, int P, float* pix_intr, float* pix_extr, void* stream) {
     REQ(wpose && wpose_intr && wfx && wfy && wux && wuy && K && Kinv && pose && calib && C >= 0 && H > 0 && W > 0, "mcnerf_camera_fwd");
-    McnCameraArgs a = {wpose, wpose_intr, wfx, wfy, wux, wuy, C, H, W, K, Kinv, pose, calib};
+    REQ((wpts_intr == nullptr) == (pix_intr == nullptr) && (wpts_extr == nullptr) == (pix_extr == nullptr) && P >= 0, "mcnerf_camera_fwd");
+    McnCameraArgs a = {wpose, wpose_intr, wfx, wfy, wux, wuy, C, H, W, K, Kinv, pose, calib, wpts_intr, wpts_extr, P, pix_intr, pix_extr};
     return check("mcnerf_camera_fwd", mcn_launch_camera_fwd(a, (hipStream_t)stream));
 }
 int mcnerf_camera_bwd(const float* wpose, const float* wpose_intr, const float* wfx, const float* wfy, const float* wux,
                       const float* wuy, int C, int H, int W, const float* dK, const float* dKinv, const float* dpose,
-                      const float* dcalib, float* d_wpose, float* d_wpose_intr, float* d_wfx, float* d_wfy, float* d_wux,
+                      const float* dcalib, const float* wpts_intr, const float* wpts_extr, int P, const float* dpix_intr,
+                      const float* dpix_extr, float* d_wpose, float* d_wpose_intr, float* d_wfx, float* d_wfy, float* d_wux,
                       float* d_wuy, void* stream) {
-    REQ(wpose && wpose_intr && wfx && wfy && wux && wuy && C >= 0 && H > 0 && W > 0, "mcnerf_camera_bwd");
+    REQ(wpose && wpose_intr && wfx && wfy && wux && wuy && C >= 0 && H > 0 && W > 0 && P >= 0, "mcnerf_camera_bwd");
     REQ(d_wpose && d_wpose_intr && d_wfx && d_wfy && d_wux && d_wuy, "mcnerf_camera_bwd");
-    McnCameraArgs a = {wpose, wpose_intr, wfx, wfy, wux, wuy, C, H, W, nullptr, nullptr, nullptr, nullptr};
-    McnCameraGrads g = {dK, dKinv, dpose, dcalib, d_wpose, d_wpose_intr, d_wfx, d_wfy, d_wux, d_wuy};
+    REQ((!dpix_intr || wpts_intr) && (!dpix_extr || wpts_extr), "mcnerf_camera_bwd");
+    McnCameraArgs a = {wpose, wpose_intr, wfx, wfy, wux, wuy, C, H, W, nullptr, nullptr, nullptr, nullptr, wpts_intr, wpts_extr, P, nullptr, nullptr};
+    McnCameraGrads g = {dK, dKinv, dpose, dcalib, dpix_intr, dpix_extr, d_wpose, d_wpose_intr, d_wfx, d_wfy, d_wux, d_wuy};
     return check("mcnerf_camera_bwd", mcn_launch_camera_bwd(a, g, (hipStream_t)stream));
+}
+int mcnerf_reproj_loss_fwd(const float* pd, const float* gt, int n, int H, int W, float* loss, void* stream) {
+    REQ(pd && gt && loss && n > 0 && H > 0 && W > 0, "mcnerf_reproj_loss_fwd");
+    return check("mcnerf_reproj_loss_fwd", mcn_launch_reproj_loss_fwd(pd, gt, n, H, W, loss, (hipStream_t)stream));
+}
+int mcnerf_reproj_loss_bwd(const float* pd, const float* gt, int n, int H, int W, const float* dloss, float* d_pd, void* stream) {
+    REQ(pd && gt && dloss && d_pd && n > 0 && H > 0 && W > 0, "mcnerf_reproj_loss_bwd");
+    return check("mcnerf_reproj_loss_bwd", mcn_launch_reproj_loss_bwd(pd, gt, n, H, W, dloss, d_pd, (hipStream_t)stream));
 }
 
 int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,

@@ -1,5 +1,7 @@
 // Fused camera parametrisation for gfx950: learnable multipliers -> K, K^-1 and
-// se(3) -> SE(3) for BOTH pose sets of every camera, forward and backward, one thread per camera.
+// se(3) -> SE(3) for BOTH pose sets of every camera, plus the calibration REPROJECTION branch (P world points per
+// camera through [R|t] and K -> pixels; get_reproject_pixels / world2cam / cam2pix, model/mc_nerf.py:147-152, 236-267),
+// forward and backward, one thread per camera; the reprojection loss (model/loss.py:45-58) is a one-workgroup kernel.
 //
 // Replaces MC_Model.add_weights2intr / add_weights2pose / add_weights2calib_pose / se3_to_SE3 /
 // taylor_A,B,C / inverse_intrinsic (model/mc_nerf.py:171-210, 269-316): ~1500 ATen dispatches per step
@@ -109,6 +111,39 @@ __device__ void se3_bwd(const float* wu, const float* g, float* dwu) {
     }
 }
 
+// pixels of P world points through one camera: cam = [R|t] [x,1], pix = K cam, (pix0 / pix2, pix1 / pix2) in the
+// reference's operation order (the matmul row sums keep the zero terms' positions)
+__device__ void reproject_fwd(const float* Rt, float fx, float fy, float ux, float uy, const float* wpts, int P, float* pix) {
+    for (int p = 0; p < P; ++p) {
+        const float x = wpts[p * 3], y = wpts[p * 3 + 1], z = wpts[p * 3 + 2];
+        float cam[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cam[i] = Rt[i * 4] * x + Rt[i * 4 + 1] * y + Rt[i * 4 + 2] * z + Rt[i * 4 + 3];
+        const float p0 = fx * cam[0] + ux * cam[2], p1 = fy * cam[1] + uy * cam[2], p2 = cam[2];
+        pix[p * 2] = p0 / p2;
+        pix[p * 2 + 1] = p1 / p2;
+    }
+}
+// backward: d pix [P,2] -> accumulated d Rt [3][4] and d (fx, fy, ux, uy)
+__device__ void reproject_bwd(const float* Rt, float fx, float fy, float ux, float uy, const float* wpts, int P, const float* dpix,
+                              float* dRt, float& dfx, float& dfy, float& dux, float& duy) {
+    for (int p = 0; p < P; ++p) {
+        const float w[4] = {wpts[p * 3], wpts[p * 3 + 1], wpts[p * 3 + 2], 1.f};
+        float cam[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cam[i] = Rt[i * 4] * w[0] + Rt[i * 4 + 1] * w[1] + Rt[i * 4 + 2] * w[2] + Rt[i * 4 + 3];
+        const float p0 = fx * cam[0] + ux * cam[2], p1 = fy * cam[1] + uy * cam[2], p2 = cam[2];
+        const float du = dpix[p * 2], dv = dpix[p * 2 + 1];
+        const float dp0 = du / p2, dp1 = dv / p2, dp2 = -(du * p0 + dv * p1) / (p2 * p2);
+        dfx += dp0 * cam[0]; dux += dp0 * cam[2]; dfy += dp1 * cam[1]; duy += dp1 * cam[2];
+        const float dcam[3] = {dp0 * fx, dp1 * fy, dp0 * ux + dp1 * uy + dp2};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dRt[i * 4 + j] += dcam[i] * w[j];
+    }
+}
+
 __global__ void camera_fwd_kernel(McnCameraArgs a) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.C) return;
@@ -122,6 +157,8 @@ __global__ void camera_fwd_kernel(McnCameraArgs a) {
     Ki[6] = 0.f; Ki[7] = 0.f; Ki[8] = 1.f;
     se3_fwd(a.wpose + c * 6, a.pose + c * 12);
     se3_fwd(a.wpose_intr + c * 6, a.calib + c * 12);
+    if (a.pix_intr && a.wpts_intr) reproject_fwd(a.calib + c * 12, fx, fy, ux, uy, a.wpts_intr + (size_t)c * a.P * 3, a.P, a.pix_intr + (size_t)c * a.P * 2);
+    if (a.pix_extr && a.wpts_extr) reproject_fwd(a.pose + c * 12, fx, fy, ux, uy, a.wpts_extr + (size_t)c * a.P * 3, a.P, a.pix_extr + (size_t)c * a.P * 2);
 }
 
 __global__ void camera_bwd_kernel(McnCameraArgs a, McnCameraGrads g) {
@@ -133,6 +170,22 @@ __global__ void camera_bwd_kernel(McnCameraArgs a, McnCameraGrads g) {
     const float* dK = g.dK ? g.dK + c * 9 : nullptr;
     const float* dKi = g.dKinv ? g.dKinv + c * 9 : nullptr;
     float dfx = 0.f, dfy = 0.f, dux = 0.f, duy = 0.f;
+    // upstream of the two SE(3) matrices: the caller's plus what flows back from the reprojected pixels
+    float gpose[12], gcalib[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { gpose[k] = g.dpose ? g.dpose[c * 12 + k] : 0.f; gcalib[k] = g.dcalib ? g.dcalib[c * 12 + k] : 0.f; }
+    const bool rp_i = g.dpix_intr && a.wpts_intr, rp_e = g.dpix_extr && a.wpts_extr;
+    if (rp_i || rp_e) {
+        float Rt[12];
+        if (rp_i) {
+            se3_fwd(a.wpose_intr + c * 6, Rt);
+            reproject_bwd(Rt, fx, fy, ux, uy, a.wpts_intr + (size_t)c * a.P * 3, a.P, g.dpix_intr + (size_t)c * a.P * 2, gcalib, dfx, dfy, dux, duy);
+        }
+        if (rp_e) {
+            se3_fwd(a.wpose + c * 6, Rt);
+            reproject_bwd(Rt, fx, fy, ux, uy, a.wpts_extr + (size_t)c * a.P * 3, a.P, g.dpix_extr + (size_t)c * a.P * 2, gpose, dfx, dfy, dux, duy);
+        }
+    }
     if (dK) { dfx += dK[0]; dux += dK[2]; dfy += dK[4]; duy += dK[5]; }
     if (dKi) {
         dfx += -dKi[0] / (fx * fx) + dKi[2] * ux / (fx * fx);
@@ -146,14 +199,45 @@ __global__ void camera_bwd_kernel(McnCameraArgs a, McnCameraGrads g) {
     g.d_wux[c] = dux * (rux > 0.f ? 1.f : (rux < 0.f ? -1.f : 0.f)) * Wf / 2.f;
     g.d_wuy[c] = duy * (ruy > 0.f ? 1.f : (ruy < 0.f ? -1.f : 0.f)) * Hf / 2.f;
     float dw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (g.dpose) se3_bwd(a.wpose + c * 6, g.dpose + c * 12, dw);
+    if (g.dpose || rp_e) se3_bwd(a.wpose + c * 6, gpose, dw);
 #pragma unroll
     for (int k = 0; k < 6; ++k) g.d_wpose[c * 6 + k] = dw[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) dw[k] = 0.f;
-    if (g.dcalib) se3_bwd(a.wpose_intr + c * 6, g.dcalib + c * 12, dw);
+    if (g.dcalib || rp_i) se3_bwd(a.wpose_intr + c * 6, gcalib, dw);
 #pragma unroll
     for (int k = 0; k < 6; ++k) g.d_wpose_intr[c * 6 + k] = dw[k];
+}
+
+// ---- reprojection loss: one workgroup, n = B * C * P points (550 at cfg 2)
+__global__ __launch_bounds__(256) void reproj_loss_fwd_kernel(const float* pd, const float* gt, int n, float inv_w2, float inv_h2, float* loss) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float ex = pd[2 * i] - gt[2 * i], ey = pd[2 * i + 1] - gt[2 * i + 1];
+        acc += ex * ex * inv_w2 + ey * ey * inv_h2;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) *loss = red[0] / (float)n;
+}
+__global__ void reproj_loss_bwd_kernel(const float* pd, const float* gt, int n, float inv_w2, float inv_h2, const float* dloss, float* d_pd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = *dloss * 2.f / (float)n;
+    d_pd[2 * i] = g * (pd[2 * i] - gt[2 * i]) * inv_w2;
+    d_pd[2 * i + 1] = g * (pd[2 * i + 1] - gt[2 * i + 1]) * inv_h2;
+}
+hipError_t mcn_launch_reproj_loss_fwd(const float* pd, const float* gt, int n, int H, int W, float* loss, hipStream_t st) {
+    hipLaunchKernelGGL(reproj_loss_fwd_kernel, dim3(1), dim3(256), 0, st, pd, gt, n, 1.0f / ((float)W * (float)W), 1.0f / ((float)H * (float)H), loss);
+    return hipGetLastError();
+}
+hipError_t mcn_launch_reproj_loss_bwd(const float* pd, const float* gt, int n, int H, int W, const float* dloss, float* d_pd, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(reproj_loss_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pd, gt, n, 1.0f / ((float)W * (float)W),
+                       1.0f / ((float)H * (float)H), dloss, d_pd);
+    return hipGetLastError();
 }
 
 hipError_t mcn_launch_camera_fwd(const McnCameraArgs& a, hipStream_t st) {

@@ -167,12 +167,23 @@ struct McnCameraArgs {
     float* Kinv;              // [C,3,3]
     float* pose;              // [C,3,4]
     float* calib;             // [C,3,4]
+    // calibration reprojection branch (model/mc_nerf.py:147-152, 236-267); any of these may be null
+    const float* wpts_intr;   // [C,P,3] world points projected through (K, calib)
+    const float* wpts_extr;   // [C,P,3] world points projected through (K, pose)
+    int P;
+    float* pix_intr;          // [C,P,2]
+    float* pix_extr;          // [C,P,2]
 };
 struct McnCameraGrads {
     const float* dK; const float* dKinv; const float* dpose; const float* dcalib;     // upstream (any may be null)
+    const float* dpix_intr; const float* dpix_extr;                                    // upstream of the reprojected pixels [C,P,2] (may be null)
     float* d_wpose; float* d_wpose_intr; float* d_wfx; float* d_wfy; float* d_wux; float* d_wuy;   // written
 };
 hipError_t mcn_launch_camera_fwd(const McnCameraArgs& a, hipStream_t st);
 hipError_t mcn_launch_camera_bwd(const McnCameraArgs& a, const McnCameraGrads& g, hipStream_t st);
+
+// fused reprojection loss (model/loss.py:45-58): mean((pd_x - gt_x)^2) / W^2 + mean((pd_y - gt_y)^2) / H^2 over n points
+hipError_t mcn_launch_reproj_loss_fwd(const float* pd, const float* gt, int n, int H, int W, float* loss, hipStream_t st);
+hipError_t mcn_launch_reproj_loss_bwd(const float* pd, const float* gt, int n, int H, int W, const float* dloss, float* d_pd, hipStream_t st);
 
 hipError_t mcn_launch_gather_gt(const unsigned char* img, int channels, const long long* pix, int n, float* out, hipStream_t st);

@@ -37,6 +37,9 @@ class MC_NeRF_Loss(nn.Module):
 
     def get_reproject_loss(self, rpro_list):
         pd, gt = rpro_list
+        if pd.is_cuda:                                   # one fused kernel each way (csrc/camera.hip)
+            from .render import ReprojLossFn
+            return ReprojLossFn.apply(pd, gt.to(pd.device), self.img_h, self.img_w)
         lx = F.mse_loss(pd[..., 0] / self.img_w, gt[..., 0] / self.img_w)
         ly = F.mse_loss(pd[..., 1] / self.img_h, gt[..., 1] / self.img_h)
         return lx + ly

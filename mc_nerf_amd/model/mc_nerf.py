@@ -338,15 +338,15 @@ class MC_Model(nn.Module):
         emb = self.nerf.emmbedding_xyz
         if epoch_type == "CAM_PARAM_EPOCH":
             emb.barf_mode = False
-            self.intr_adj, self.pose_adj, self.calib_pose_adj = self.add_weights2param(True, True, True)
-            loss_dict["intr"] = [self.get_reproject_pixels(intr_wpts, self.intr_adj, self.calib_pose_adj), intr_pts]
-            loss_dict["extr"] = [self.get_reproject_pixels(extr_wpts, self.intr_adj, self.pose_adj), extr_pts]
+            self.intr_adj, self.pose_adj, self.calib_pose_adj = self.add_weights2param(True, True, True, intr_wpts, extr_wpts)
+            loss_dict["intr"] = [self._reproject(intr_wpts, self.intr_adj, self.calib_pose_adj, 0), intr_pts]
+            loss_dict["extr"] = [self._reproject(extr_wpts, self.intr_adj, self.pose_adj, 1), extr_pts]
             self.opt_idx = 0
         else:
             joint = epoch_type == "GLOBAL_OPTIM_EPOCH"
             emb.barf_mode = joint                                   # :74 / :86
-            self.intr_adj, self.pose_adj, self.calib_pose_adj = self.add_weights2param(True, joint, True)
-            loss_dict["intr"] = [self.get_reproject_pixels(intr_wpts, self.intr_adj, self.calib_pose_adj), intr_pts]
+            self.intr_adj, self.pose_adj, self.calib_pose_adj = self.add_weights2param(True, joint, True, intr_wpts, None)
+            loss_dict["intr"] = [self._reproject(intr_wpts, self.intr_adj, self.calib_pose_adj, 0), intr_pts]
             kinv = self.intr_inv_adj[cam] if self.intr_inv_adj is not None else \
                 self.inverse_intrinsic(self.intr_adj[cam:cam + 1])[0]
             # pixel subset first (same device randperm as :329), rays only for those pixels
@@ -397,15 +397,22 @@ class MC_Model(nn.Module):
     # On the GPU all six parameter tensors go through ONE fused kernel each way (CameraFn, csrc/camera.hip;
     # SURVEY.md 8f row f1).  The per-piece torch methods below restate the same maths; they serve host tensors
     # (the CPU plumbing tests of the camera-only stage) and API compatibility.
-    def add_weights2param(self, intr=True, extr=True, calib_extr=False):
+    def add_weights2param(self, intr=True, extr=True, calib_extr=False, intr_wpts=None, extr_wpts=None):
+        """K, pose, calib pose of all cameras.  On the GPU the fused kernel also projects the calibration points
+        (`intr_wpts` through (K, calib pose), `extr_wpts` through (K, pose); [1,C,P,3] as the loader delivers them, :374-386):
+        the pixels are kept in `self._reproj` for `_reproject`, so the whole camera preamble is one launch each way."""
         self.intr_inv_adj = None
+        self._reproj = [None, None]
         if self.weights_pose.is_cuda:
             det = lambda t, on: t if on else t.detach()
-            K, Kinv, pose, calib = CameraFn.apply(det(self.weights_pose, extr), det(self.weights_pose_intr, calib_extr),
-                                                  det(self.weights_fx, intr), det(self.weights_fy, intr),
-                                                  det(self.weights_ux, intr), det(self.weights_uy, intr),
-                                                  self.img_h, self.img_w)
+            pts = [None if t is None else t.reshape(-1, t.shape[-2], 3) for t in (intr_wpts, extr_wpts)]
+            K, Kinv, pose, calib, pi, pe = CameraFn.apply(det(self.weights_pose, extr), det(self.weights_pose_intr, calib_extr),
+                                                          det(self.weights_fx, intr), det(self.weights_fy, intr),
+                                                          det(self.weights_ux, intr), det(self.weights_uy, intr),
+                                                          self.img_h, self.img_w, pts[0], pts[1])
             self.intr_inv_adj = Kinv
+            self._reproj = [None if pi is None else pi.reshape(intr_wpts.shape[:-1] + (2,)),
+                            None if pe is None else pe.reshape(extr_wpts.shape[:-1] + (2,))]
             return K, pose, calib
         return (self.add_weights2intr(self.img_h, self.img_w, adj=intr), self.add_weights2pose(adj=extr),
                 self.add_weights2calib_pose(adj=calib_extr))
@@ -463,6 +470,11 @@ class MC_Model(nn.Module):
         return torch.cat([R, V @ u[..., None]], dim=-1)
 
     # ------------------------------------------------------------------ reprojection branch (:147-152, 236-267)
+    def _reproject(self, tag_wpts, intr_adj, pose_adj, which):
+        """The pixels the fused camera kernel already produced (GPU), else the tensor-op restatement."""
+        got = getattr(self, "_reproj", [None, None])[which]
+        return got if got is not None else self.get_reproject_pixels(tag_wpts, intr_adj, pose_adj)
+
     def get_reproject_pixels(self, tag_wpts, intr_adj, pose_adj):
         """Projects calibration points [B,C,P,3] through [R|t] and K -> pixel coords [B,C,P,2]."""
         ones = torch.ones_like(tag_wpts[..., :1])

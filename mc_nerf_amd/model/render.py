@@ -211,20 +211,39 @@ class RaygenFn(torch.autograd.Function):
 
 
 class CameraFn(torch.autograd.Function):
-    """K, Kinv, pose, calib_pose = f(weights_pose, weights_pose_intr, weights_fx, weights_fy, weights_ux, weights_uy)
-    for all cameras in one fused kernel each way (reference: model/mc_nerf.py:171-210, 269-316)."""
+    """K, Kinv, pose, calib_pose, pix_intr, pix_extr = f(weights_pose, weights_pose_intr, weights_fx, weights_fy, weights_ux,
+    weights_uy; calibration world points) for all cameras in one fused kernel each way (reference: model/mc_nerf.py:171-210,
+    269-316 and the reprojection branch :147-152, 236-267).  wpts_intr / wpts_extr [C,P,3] may be None (pixels not wanted)."""
 
     @staticmethod
-    def forward(ctx, wpose, wpose_intr, wfx, wfy, wux, wuy, H, W):
+    def forward(ctx, wpose, wpose_intr, wfx, wfy, wux, wuy, H, W, wpts_intr=None, wpts_extr=None):
         args = [t.contiguous().float() for t in (wpose, wpose_intr, wfx, wfy, wux, wuy)]
-        K, Kinv, pose, calib = ops.camera_fwd(*args, H, W)
+        pts = [None if t is None else t.contiguous().float() for t in (wpts_intr, wpts_extr)]
+        K, Kinv, pose, calib, pi, pe = ops.camera_fwd(*args, H, W, pts[0], pts[1])
         ctx.save_for_backward(*args)
+        ctx.pts = pts
         ctx.hw = (H, W)
         ctx.set_materialize_grads(False)
-        return K, Kinv, pose, calib
+        return K, Kinv, pose, calib, pi, pe
 
     @staticmethod
-    def backward(ctx, dK, dKinv, dpose, dcalib):
+    def backward(ctx, dK, dKinv, dpose, dcalib, dpi, dpe):
         args = ctx.saved_tensors
-        grads = ops.camera_bwd(*args, ctx.hw[0], ctx.hw[1], dK, dKinv, dpose, dcalib)
-        return tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[:6])) + (None, None)
+        grads = ops.camera_bwd(*args, ctx.hw[0], ctx.hw[1], dK, dKinv, dpose, dcalib, ctx.pts[0], ctx.pts[1], dpi, dpe)
+        return tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[:6])) + (None, None, None, None)
+
+
+class ReprojLossFn(torch.autograd.Function):
+    """MC_NeRF_Loss.get_reproject_loss (model/loss.py:45-58) as one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, pd, gt, H, W):
+        pd, gt = pd.contiguous().float(), gt.contiguous().float()
+        ctx.save_for_backward(pd, gt)
+        ctx.hw = (H, W)
+        return ops.reproj_loss_fwd(pd, gt, H, W)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        pd, gt = ctx.saved_tensors
+        return ops.reproj_loss_bwd(pd, gt, ctx.hw[0], ctx.hw[1], dloss.contiguous().float()), None, None, None

@@ -296,26 +296,52 @@ def cap_random(idx: Tensor, count: Tensor, max_rows: int, keep: int, seed: Tenso
     return idx2, count2
 
 
-def camera_fwd(wpose: Tensor, wpose_intr: Tensor, wfx: Tensor, wfy: Tensor, wux: Tensor, wuy: Tensor, H: int, W: int):
-    """-> K [C,3,3], Kinv [C,3,3], pose [C,3,4], calib_pose [C,3,4]"""
+def camera_fwd(wpose: Tensor, wpose_intr: Tensor, wfx: Tensor, wfy: Tensor, wux: Tensor, wuy: Tensor, H: int, W: int,
+               wpts_intr: Optional[Tensor] = None, wpts_extr: Optional[Tensor] = None):
+    """-> K [C,3,3], Kinv [C,3,3], pose [C,3,4], calib_pose [C,3,4], pix_intr [C,P,2] | None, pix_extr [C,P,2] | None
+    (pixels of the calibration points wpts_* [C,P,3] through (K, calib) / (K, pose))."""
     C, dev = wpose.shape[0], wpose.device
     K = torch.empty(C, 3, 3, dtype=torch.float32, device=dev)
     Kinv = torch.empty_like(K)
     pose = torch.empty(C, 3, 4, dtype=torch.float32, device=dev)
     calib = torch.empty_like(pose)
+    P = 0
+    for w in (wpts_intr, wpts_extr):
+        if w is not None:
+            P = w.shape[1]
+    pi = torch.empty(C, P, 2, dtype=torch.float32, device=dev) if wpts_intr is not None else None
+    pe = torch.empty(C, P, 2, dtype=torch.float32, device=dev) if wpts_extr is not None else None
     _lib.call("mcnerf_camera_fwd", _p(wpose), _p(wpose_intr), _p(wfx), _p(wfy), _p(wux), _p(wuy), C, int(H), int(W),
-              _p(K), _p(Kinv), _p(pose), _p(calib), _stream())
-    return K, Kinv, pose, calib
+              _p(K), _p(Kinv), _p(pose), _p(calib), _p(wpts_intr), _p(wpts_extr), int(P), _p(pi), _p(pe), _stream())
+    return K, Kinv, pose, calib, pi, pe
 
 
-def camera_bwd(wpose, wpose_intr, wfx, wfy, wux, wuy, H: int, W: int, dK, dKinv, dpose, dcalib):
+def camera_bwd(wpose, wpose_intr, wfx, wfy, wux, wuy, H: int, W: int, dK, dKinv, dpose, dcalib,
+               wpts_intr=None, wpts_extr=None, dpix_intr=None, dpix_extr=None):
     C = wpose.shape[0]
     outs = [torch.empty_like(t) for t in (wpose, wpose_intr, wfx, wfy, wux, wuy)]
     c = lambda t: None if t is None else t.contiguous()
-    dK, dKinv, dpose, dcalib = c(dK), c(dKinv), c(dpose), c(dcalib)
+    dK, dKinv, dpose, dcalib, dpix_intr, dpix_extr = c(dK), c(dKinv), c(dpose), c(dcalib), c(dpix_intr), c(dpix_extr)
+    P = 0
+    for w in (wpts_intr, wpts_extr):
+        if w is not None:
+            P = w.shape[1]
     _lib.call("mcnerf_camera_bwd", _p(wpose), _p(wpose_intr), _p(wfx), _p(wfy), _p(wux), _p(wuy), C, int(H), int(W),
-              _p(dK), _p(dKinv), _p(dpose), _p(dcalib), *[_p(o) for o in outs], _stream())
+              _p(dK), _p(dKinv), _p(dpose), _p(dcalib), _p(wpts_intr), _p(wpts_extr), int(P), _p(dpix_intr), _p(dpix_extr),
+              *[_p(o) for o in outs], _stream())
     return outs
+
+
+def reproj_loss_fwd(pd: Tensor, gt: Tensor, H: int, W: int) -> Tensor:
+    loss = torch.empty((), dtype=torch.float32, device=pd.device)
+    _lib.call("mcnerf_reproj_loss_fwd", _p(pd), _p(gt), pd.numel() // 2, int(H), int(W), _p(loss), _stream())
+    return loss
+
+
+def reproj_loss_bwd(pd: Tensor, gt: Tensor, H: int, W: int, dloss: Tensor) -> Tensor:
+    d = torch.empty_like(pd)
+    _lib.call("mcnerf_reproj_loss_bwd", _p(pd), _p(gt), pd.numel() // 2, int(H), int(W), _p(dloss), _p(d), _stream())
+    return d
 
 
 def gather_gt(image_u8: Tensor, pix: Tensor) -> Tensor:

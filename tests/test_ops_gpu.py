@@ -351,7 +351,7 @@ def test_camera_parametrisation_fwd_bwd(gpu_device):
     gp, gc = torch.randn(C, 3, 4, generator=g), torch.randn(C, 3, 4, generator=g)
     ((K * gK).sum() + (Kinv * gKi).sum() + (pose * gp).sum() + (calib * gc).sum()).backward()
     dl = [t.detach().to(dev) for t in leaves]
-    K2, Ki2, p2, c2 = ops.camera_fwd(*dl, H, W)
+    K2, Ki2, p2, c2, _, _ = ops.camera_fwd(*dl, H, W)
     assert maxerr(K2, K) < 1e-4 and maxerr(p2, pose) < 2e-6 and maxerr(c2, calib) < 2e-6
     assert maxerr(Ki2, Kinv) < 1e-7 + 1e-6 * float(Kinv.abs().max())
     grads = ops.camera_bwd(*dl, H, W, gK.to(dev), gKi.to(dev), gp.to(dev), gc.to(dev))
@@ -361,6 +361,53 @@ def test_camera_parametrisation_fwd_bwd(gpu_device):
     # null upstreams are allowed
     g2 = ops.camera_bwd(*dl, H, W, None, None, gp.to(dev), None)
     assert float(g2[1].abs().max()) == 0.0 and float(g2[2].abs().max()) == 0.0 and maxerr(g2[0], leaves[0].grad) > 0
+
+
+def test_camera_reprojection_branch_and_loss(gpu_device):
+    """SURVEY 8f row f1, second half: the calibration reprojection (get_reproject_pixels, model/mc_nerf.py:147-152, 236-267)
+    inside the fused camera kernels and the reprojection loss kernel (model/loss.py:45-58), forward and backward, against
+    autograd through the oracle's camera parametrisation + the reference formulas in tensor ops."""
+    ops = _ops()
+    dev = gpu_device
+    C, P, H, W = 11, 5, 600, 800
+    g = torch.Generator().manual_seed(8)
+    wp = torch.randn(C, 6, generator=g) * 0.3
+    wp[:, 5] += 4.0                                             # points end up in front of the cameras
+    wpi = torch.randn(C, 6, generator=g) * 0.3
+    wpi[:, 5] += 4.0
+    ws = [1.0 + 0.2 * torch.randn(C, generator=g) for _ in range(4)]
+    leaves = [t.clone().requires_grad_(True) for t in [wp, wpi] + ws]
+    wi = torch.randn(C, P, 3, generator=g) * 0.5
+    we = torch.randn(C, P, 3, generator=g) * 0.5
+    gt_i, gt_e = torch.rand(1, C, P, 2, generator=g) * 800, torch.rand(1, C, P, 2, generator=g) * 600
+
+    def project(wpts, K, pose):                                 # the reference's tensor ops (:236-267)
+        wh = torch.cat([wpts, torch.ones_like(wpts[..., :1])], -1)
+        cam = wh @ pose.transpose(-2, -1)
+        pix = cam @ K.transpose(-2, -1)
+        return pix[..., :2] / pix[..., 2:]
+
+    def loss_ref(pd, gt):
+        return ((pd[..., 0] - gt[..., 0]) / W).pow(2).mean() + ((pd[..., 1] - gt[..., 1]) / H).pow(2).mean()
+    K = O.intrinsics_from_weights(H, W, *leaves[2:])
+    pose, calib = O.se3_to_SE3(leaves[0]), O.se3_to_SE3(leaves[1])
+    pi_ref, pe_ref = project(wi, K, calib), project(we, K, pose)
+    l_ref = loss_ref(pi_ref.unsqueeze(0), gt_i) + 3.0 * loss_ref(pe_ref.unsqueeze(0), gt_e)
+    l_ref.backward()
+
+    from mc_nerf_amd.model.render import CameraFn, ReprojLossFn
+    dl = [t.detach().to(dev).requires_grad_(True) for t in leaves]
+    _, _, _, _, pi, pe = CameraFn.apply(*dl, H, W, wi.to(dev), we.to(dev))
+    assert maxerr(pi, pi_ref) < 2e-3 and maxerr(pe, pe_ref) < 2e-3       # pixels (values of several hundred): ~1e-6 relative
+    l = ReprojLossFn.apply(pi.unsqueeze(0), gt_i.to(dev), H, W) + 3.0 * ReprojLossFn.apply(pe.unsqueeze(0), gt_e.to(dev), H, W)
+    assert abs(float(l) - float(l_ref)) < 1e-5 * max(1.0, abs(float(l_ref)))
+    l.backward()
+    for got, leaf in zip(dl, leaves):
+        ref = leaf.grad
+        assert maxerr(got.grad, ref) < 5e-5 * max(1.0, float(ref.abs().max())), (maxerr(got.grad, ref), float(ref.abs().max()))
+    # only one branch requested
+    _, _, _, _, pi2, pe2 = CameraFn.apply(*[t.detach() for t in dl], H, W, wi.to(dev), None)
+    assert pe2 is None and torch.equal(pi2, pi.detach())
 
 
 def test_gather_gt_from_device_resident_images(gpu_device):
