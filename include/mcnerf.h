@@ -225,10 +225,14 @@ int mcnerf_reproj_loss_bwd(const float* pd, const float* gt, int n, int H, int W
 /* Fused multi-tensor Rectified-Adam step (one launch for all tensors of a param group).
  * Replaces the per-tensor loop of RAdam.step (model/net_utils.py:38-99).  The arrays of n_tensors device
  * pointers / sizes live on the HOST; step_size and `rectified` (N_sma >= 5) are the host-side scalars of the
- * reference's step-size cache (model/net_utils.py:67-86) for the tensors' common step count. */
+ * reference's step-size cache (model/net_utils.py:67-86) for the tensors' common step count.
+ * guard (device uint32[2], or NULL): overflow guard of the reduced-precision modes -- guard[0] is raised when any gradient
+ * of the call is inf / NaN, the whole call then leaves parameters and moments untouched and guard[1] counts the skipped
+ * step (the caller zero-initialises guard[1] once and reads it whenever it likes; no synchronisation here).  Note: a call
+ * of more than 64 tensors is split into launches of 64; the check covers each launch's tensors before its update. */
 int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const long long* sizes, float lr, float beta1, float beta2, float eps,
-                      float weight_decay, float step_size, int rectified, void* stream);
+                      float weight_decay, float step_size, int rectified, uint32_t* guard, void* stream);
 
 #ifdef __cplusplus
 }

@@ -334,7 +334,7 @@ int mcnerf_reproj_loss_bwd(const float* pd, const float* gt, int n, int H, int W
 
 int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const long long* sizes, float lr, float beta1, float beta2, float eps,
-                      float weight_decay, float step_size, int rectified, void* stream) {
+                      float weight_decay, float step_size, int rectified, uint32_t* guard, void* stream) {
     REQ(n_tensors >= 0 && params && grads && exp_avg && exp_avg_sq && sizes, "mcnerf_radam_step");
     for (int t0 = 0; t0 < n_tensors; t0 += MCN_RADAM_MAXT) {           // 64 tensors per launch
         McnRadamTable t;
@@ -349,7 +349,7 @@ int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* g
             t.first_block[i] = blocks;
             blocks += (int)((sizes[t0 + i] + MCN_RADAM_CHUNK - 1) / MCN_RADAM_CHUNK);
         }
-        const int rc = check("mcnerf_radam_step", mcn_launch_radam(t, blocks, (hipStream_t)stream));
+        const int rc = check("mcnerf_radam_step", mcn_launch_radam(t, blocks, guard, t0 == 0, (hipStream_t)stream));
         if (rc) return rc;
     }
     return 0;

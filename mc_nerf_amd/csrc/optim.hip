@@ -9,7 +9,29 @@
 //   otherwise (step_size>0): p -= wd*lr*p ;  p -= step_size*lr * m
 #include "mcnerf_kernels.h"
 
-__global__ __launch_bounds__(256) void radam_kernel(McnRadamTable t) {
+// Overflow guard: the 16-bit precision modes carry range limits (f16 operands saturate to inf, which the fp32
+// accumulators turn into NaN gradients); one non-finite gradient would poison the flat parameter buffers for good.
+// radam_check_kernel raises guard[0] if any gradient of the group is non-finite; radam_kernel then leaves parameters
+// and moments untouched and counts the skipped step in guard[1] (read by the host whenever it likes: no sync per step).
+__global__ __launch_bounds__(256) void radam_check_kernel(McnRadamTable t, unsigned* guard) {
+    int ti = 0;
+    while (ti + 1 < t.n_tensors && (int)blockIdx.x >= t.first_block[ti + 1]) ++ti;
+    const long long base = (long long)((int)blockIdx.x - t.first_block[ti]) * MCN_RADAM_CHUNK;
+    const float* __restrict__ g = t.g[ti];
+    const long long n = t.n[ti];
+    bool bad = false;
+    for (long long i = base + threadIdx.x; i < base + MCN_RADAM_CHUNK && i < n; i += 256) {
+        const unsigned b = __float_as_uint(g[i]);
+        bad |= (b & 0x7F800000u) == 0x7F800000u;              // inf or NaN
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(guard, 1u);
+}
+
+__global__ __launch_bounds__(256) void radam_kernel(McnRadamTable t, unsigned* guard) {
+    if (guard && guard[0]) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&guard[1], 1u);
+        return;
+    }
     // block -> (tensor, chunk): blocks are dealt to tensors by their precomputed first-block index
     int ti = 0;
     while (ti + 1 < t.n_tensors && (int)blockIdx.x >= t.first_block[ti + 1]) ++ti;
@@ -37,8 +59,15 @@ __global__ __launch_bounds__(256) void radam_kernel(McnRadamTable t) {
     }
 }
 
-hipError_t mcn_launch_radam(const McnRadamTable& t, int n_blocks, hipStream_t st) {
+hipError_t mcn_launch_radam(const McnRadamTable& t, int n_blocks, unsigned* guard, bool first_of_group, hipStream_t st) {
     if (n_blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(radam_kernel, dim3(n_blocks), dim3(256), 0, st, t);
+    if (guard) {
+        if (first_of_group) {
+            hipError_t e = hipMemsetAsync(guard, 0, sizeof(unsigned), st);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(radam_check_kernel, dim3(n_blocks), dim3(256), 0, st, t, guard);
+    }
+    hipLaunchKernelGGL(radam_kernel, dim3(n_blocks), dim3(256), 0, st, t, guard);
     return hipGetLastError();
 }

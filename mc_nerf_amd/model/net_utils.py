@@ -18,6 +18,7 @@ class RAdam(Optimizer):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("invalid RAdam hyper-parameter")
         self.degenerated_to_sgd = degenerated_to_sgd
+        self._guard = {}            # device -> int32[2]: [0] raised by a non-finite gradient this step, [1] skipped steps so far
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                         buffer=[[None, None, None] for _ in range(10)])
         super().__init__(params, defaults)
@@ -65,6 +66,17 @@ class RAdam(Optimizer):
                 self._step_fused(ps, group, slot[1], slot[2])
         return loss
 
+    def skipped_steps(self) -> int:
+        """Steps the fused kernel refused because a gradient was inf / NaN (overflow of a reduced-precision mode): the
+        parameters and moments of such a step are left untouched.  Synchronises; call it at epoch ends / checkpoints."""
+        return int(sum(int(g[1].item()) for g in self._guard.values()))
+
+    def raise_on_overflow(self):
+        n = self.skipped_steps()
+        if n:
+            raise _lib.McnerfError(f"{n} optimiser step(s) skipped: non-finite gradients (operand range of the 16-bit / split-f16 "
+                                   "precision modes exceeded -- switch `precision` to 'f32' or lower the learning rate)")
+
     @staticmethod
     def _step_host(p, g, st, group, n_sma, step_size):
         beta1, beta2 = group["betas"]
@@ -97,7 +109,10 @@ class RAdam(Optimizer):
                 PtrArr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in ps]),
                 SizeArr(*[p.numel() for p in ps]))
         beta1, beta2 = group["betas"]
-        with torch.cuda.device(ps[0].device):
+        dev = ps[0].device
+        if dev not in self._guard:
+            self._guard[dev] = torch.zeros(2, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
             _lib.call("mcnerf_radam_step", n, *[ctypes.cast(a, ctypes.c_void_p) for a in args],
                       float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]),
-                      float(step_size), int(n_sma >= 5), torch.cuda.current_stream().cuda_stream)
+                      float(step_size), int(n_sma >= 5), self._guard[dev].data_ptr(), torch.cuda.current_stream().cuda_stream)

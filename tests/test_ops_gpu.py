@@ -330,6 +330,39 @@ def test_fused_radam_matches_host_arithmetic(gpu_device):
     assert og.state[gpu[2]]["step"] == 8 and og.state[gpu[0]]["step"] == 9
 
 
+def test_fused_radam_overflow_guard(gpu_device):
+    """A non-finite gradient (operand range of a reduced-precision mode exceeded) must not reach the parameters: the fused
+    step is skipped as a whole (parameters and moments untouched), counted, and reported loudly on request."""
+    from mc_nerf_amd.model import RAdam
+    from mc_nerf_amd import _lib
+    dev = gpu_device
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in ((300, 7), (5000,), (3,))]
+    opt = RAdam(ps, lr=1e-2, weight_decay=1e-3)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    opt.step()
+    before = [p.detach().clone() for p in ps]
+    m_before = [opt.state[p]["exp_avg"].clone() for p in ps]
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    ps[1].grad[4321] = float("nan")
+    opt.step()                                        # skipped
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, ps))
+    assert all(torch.equal(a, opt.state[p]["exp_avg"]) for a, p in zip(m_before, ps))
+    assert opt.skipped_steps() == 1
+    ps[1].grad[4321] = float("inf")
+    opt.step()
+    assert opt.skipped_steps() == 2
+    with pytest.raises(_lib.McnerfError):
+        opt.raise_on_overflow()
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    opt.step()                                        # finite again: the update goes through
+    assert not torch.equal(before[0], ps[0].detach()) and opt.skipped_steps() == 2
+    assert all(bool(torch.isfinite(p).all()) for p in ps)
+
+
 def test_camera_parametrisation_fwd_bwd(gpu_device):
     """Fused camera kernel vs the oracle (itself pinned to the reference by golden G9), incl. abs() on a negative
     multiplier, a zero rotation (theta = 0) and a near-pi rotation."""
