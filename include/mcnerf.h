@@ -82,6 +82,14 @@ int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const fl
                    float* act_save, long long capacity, float* enc_save, float* sh_save, uint32_t* mask_save,
                    void* stream);
 
+/* The two modules of model/net_block.py as stand-alone forward calls (exact fp32 MFMA; the render path never materialises
+ * these tensors):
+ *   mcnerf_encode   = SinCosEmbedding.forward (:20-35): x [n,3], barf_w [10] -> out [n,63];
+ *   mcnerf_mlp_apply = CorseFine_NeRF.forward (:67-78): x_enc [n,63], dirs [n,3] -> out [n,4] = (sigma_raw, r, g, b). */
+int mcnerf_encode(const float* x, const float* barf_w, int n, float* out, void* stream);
+int mcnerf_mlp_apply(int depth, int width, int skip, const float* params, const float* packed, const float* x_enc,
+                     const float* dirs, int n, float* out, void* stream);
+
 /* mcnerf_mlp_fwd in the split-f16 precision mode: identical arguments, outputs and workspace formats;
  * `packed16` comes from mcnerf_pack_weights_f16x3.  Activations must stay below 8188 in magnitude. */
 int mcnerf_mlp_fwd_f16x3(int depth, int width, int skip, const float* params, const void* packed16,

@@ -98,6 +98,22 @@ int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const fl
     return check("mcnerf_mlp_fwd", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
 }
 
+int mcnerf_encode(const float* x, const float* barf_w, int n, float* out, void* stream) {
+    REQ(x && barf_w && out && n >= 0, "mcnerf_encode");
+    return check("mcnerf_encode", mcn_launch_encode(x, barf_w, n, out, (hipStream_t)stream));
+}
+int mcnerf_mlp_apply(int depth, int width, int skip, const float* params, const float* packed, const float* x_enc,
+                     const float* dirs, int n, float* out, void* stream) {
+    REQ(net_ok(depth, width, skip) && params && packed && x_enc && dirs && out && n >= 0, "mcnerf_mlp_apply");
+    McnMlpFwdArgs a;
+    a.lay = mcn_make_layout(depth, width, skip);
+    a.params = params; a.packed = packed; a.rays_o = dirs; a.rays_d = dirs; a.zgrid = dirs; a.jitter = nullptr;      // positions are not used:
+    a.barf_w = dirs; a.idx = nullptr; a.count = nullptr; a.max_rows = 0; a.n_rays = n; a.S = 1;                       // the encodings come from x_enc
+    a.out = out; a.act_save = nullptr; a.act_stride = 0; a.enc_save = nullptr; a.sh_save = nullptr; a.mask_save = nullptr;
+    a.enc_in = x_enc;
+    return check("mcnerf_mlp_apply", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
+}
+
 int mcnerf_mlp_fwd_f16x3(int depth, int width, int skip, const float* params, const void* packed16,
                    const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
                    const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,

@@ -32,7 +32,15 @@ struct FwdSmem {
 // Channel order (model/net_block.py:22-33): [x,y,z, per coord c: sin(2^f c) f=0..9, cos(2^f c) f=0..9],
 // each multiplied by the BARF weight of its frequency (all ones when BARF is off).
 template <int MT, int XW>
-__device__ __forceinline__ void write_encoding(float* X, const float* sxyz, const float* barf_w, int tid, int nthreads) {
+__device__ __forceinline__ void write_encoding(float* X, const float* sxyz, const float* barf_w, int tid, int nthreads,
+                                               const float* enc_in = nullptr, long long row0 = 0, long long total = 0) {
+    if (enc_in) {          // caller-supplied encodings [rows][63] (the stand-alone CorseFine_NeRF.forward, model/net_block.py:67-78)
+        for (int it = tid; it < MT * MCN_ENCP; it += nthreads) {
+            const int m = it / MCN_ENCP, ch = it - m * MCN_ENCP;
+            X[mcn_swz(m, ch, XW)] = (ch < MCN_ENC && row0 + m < total) ? enc_in[(size_t)(row0 + m) * MCN_ENC + ch] : 0.f;
+        }
+        return;
+    }
     for (int it = tid; it < MT * 30; it += nthreads) {
         const int m = it / 30, cf = it - m * 30;
         const int c = cf / 10, f = cf - c * 10;
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
         saddr[m] = addr;
     }
     __syncthreads();
-    write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT);
+    write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT, a.enc_in, row0, total);
     __syncthreads();
     if (SAVE) {   // encoded inputs are the X operand of dW for layer 0 and the skip layer
         for (int it = tid; it < MT * 16; it += NT) {
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, KSH, pk + (L.fH[l] >> 2) + (wn * NI) * KSH * 64, lane);
             if (l == L.skip) {
                 __syncthreads();                       // everyone finished reading h from X
-                write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT);
+                write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT, a.enc_in, row0, total);
                 __syncthreads();
                 mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_ENCP / 8, pk + (L.fEncS >> 2) + (wn * NI) * (MCN_ENCP / 8) * 64, lane);
             }

@@ -196,6 +196,27 @@ hipError_t mcn_launch_cap_random(const int2* idx_in, const int* count, int max_r
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ stand-alone positional encoding
+// SinCosEmbedding.forward (model/net_block.py:20-35): [n,3] -> [n,63] = [x, per axis sin(2^f x) f=0..9, cos(2^f x) f=0..9]
+// times the per-frequency BARF weights.  (The render path computes the same inside the fused MLP kernels.)
+__global__ __launch_bounds__(256) void encode_kernel(const float* x, const float* barf_w, int n, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 30) return;
+    const int m = i / 30, cf = i - m * 30, c = cf / 10, f = cf - c * 10;
+    const float xv = x[m * 3 + c];
+    float s, co;
+    mcn_sincos(xv * (float)(1 << f), s, co);
+    const float w = barf_w[f];
+    out[(size_t)m * MCN_ENC + 3 + c * 20 + f] = s * w;
+    out[(size_t)m * MCN_ENC + 3 + c * 20 + 10 + f] = co * w;
+    if (f == 0) out[(size_t)m * MCN_ENC + c] = xv;
+}
+hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, float* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(encode_kernel, dim3((n * 30 + 255) / 256), dim3(256), 0, st, x, barf_w, n, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ ray generation
 // d = normalize(R^T K^-1 [u+.5, v+.5, 1]^T), o = -R^T t, following the reference's op order
 // (pix @ K^-T, lift, @ pose_inv^T, minus origin, normalise) so results agree to ~1e-7.

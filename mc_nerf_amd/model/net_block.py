@@ -50,8 +50,13 @@ class SinCosEmbedding(nn.Module):
         k = torch.arange(L, dtype=torch.float32)
         return (1.0 - torch.cos(torch.clamp(alpha - k, 0.0, 1.0) * math.pi)) / 2.0
 
+    @torch.no_grad()
     def forward(self, x, step_r):
-        raise NotImplementedError("the encoding is fused into the HIP MLP kernels; use NeRF_Model")
+        """Reference :20-35: [..., 3] -> [..., 63].  Stand-alone, forward-only call of the HIP encoding kernel (the render
+        path computes the encoding inside the fused MLP kernels and differentiates it there)."""
+        flat = x.reshape(-1, 3).float().contiguous()
+        out = ops.encode(flat, self.barf_weights(step_r).to(flat.device))
+        return out.reshape(*x.shape[:-1], self.out_channels)
 
 
 class CorseFine_NeRF(nn.Module):
@@ -120,5 +125,11 @@ class CorseFine_NeRF(nn.Module):
         return [flat_grad[off:off + p.numel()].view(p.shape)
                 for p, off in zip(self.ordered_parameters(), self._offsets)]
 
+    @torch.no_grad()
     def forward(self, x, dirs):
-        raise NotImplementedError("CorseFine_NeRF runs inside the fused HIP kernels; use NeRF_Model")
+        """Reference :67-78: encoded positions x [M,63] and view directions dirs [M,3] -> [M,4] = (sigma_raw, rgb).
+        Stand-alone, forward-only call of the exact-fp32 fused kernel on caller-supplied encodings (training
+        differentiates through the fused NeRF_Model.render_rays_train)."""
+        flat = self.flat_params()
+        packed = ops.pack_weights(self.net, flat, precision="f32")
+        return ops.mlp_apply(self.net, flat, packed, x.float().contiguous(), dirs.float().contiguous())

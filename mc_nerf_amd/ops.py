@@ -199,6 +199,22 @@ def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
               _p(save.mask, torch.int32) if save else None, _stream())
 
 
+def encode(x: Tensor, barf_w: Tensor) -> Tensor:
+    """SinCosEmbedding.forward (model/net_block.py:20-35): [n,3] -> [n,63]."""
+    n = x.shape[0]
+    out = torch.empty(n, 63, dtype=torch.float32, device=x.device)
+    _lib.call("mcnerf_encode", _p(x), _p(barf_w), n, _p(out), _stream())
+    return out
+
+
+def mlp_apply(net: Net, params: Tensor, packed: Tensor, x_enc: Tensor, dirs: Tensor) -> Tensor:
+    """CorseFine_NeRF.forward (model/net_block.py:67-78) on given encodings: [n,63], [n,3] -> [n,4] (exact-fp32 kernel)."""
+    n = x_enc.shape[0]
+    out = torch.empty(n, 4, dtype=torch.float32, device=x_enc.device)
+    _lib.call("mcnerf_mlp_apply", *net.triple, _p(params), _p(packed), _p(x_enc), _p(dirs), n, _p(out), _stream())
+    return out
+
+
 def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, zgrid: Tensor,
             jitter: Optional[Tensor], barf_w: Tensor, out: Tensor, d_out: Tensor, save: MlpSave,
             dy: Tensor, dsh: Tensor, d_rays_o: Optional[Tensor], d_rays_d: Optional[Tensor],

@@ -582,3 +582,32 @@ def test_randomised_configs_match_oracle(gpu_device):
     res = [one_case(rng, gpu_device, verbose=False) for _ in range(14)]
     assert not any(r is False for r in res)
     assert sum(1 for r in res if r is True) >= 8
+
+
+def test_standalone_module_forwards_match_reference_modules(gpu_device):
+    """SinCosEmbedding.forward and CorseFine_NeRF.forward (model/net_block.py:20-35, 67-78) as stand-alone calls: against the
+    oracle (pinned to the reference's modules by goldens G1 / G3), BARF on and off, ragged row count."""
+    from mc_nerf_amd.model.net_block import CorseFine_NeRF, SinCosEmbedding
+    dev = gpu_device
+    cfg = O.RenderCfg(samples=32, scale=2, coarse=O.NetCfg(4, 128, (2,)), fine=O.NetCfg(8, 256, (4,)), barf_mode=True,
+                      barf_start=0.3, barf_end=0.8)
+    sp = make_sys_param(cfg, device=str(dev))
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(777, 3, generator=g) - 0.5) * 7.0
+    dirs = torch.nn.functional.normalize(torch.randn(777, 3, generator=g), dim=-1)
+    emb = SinCosEmbedding(sp)
+    for step_r in (0.1, 0.55, 0.95):
+        enc = emb(x.to(dev), step_r)
+        assert enc.shape == (777, 63)
+        assert float((enc.cpu() - O.embed(x, step_r, cfg)).abs().max()) < 2e-6
+    emb.barf_mode = False
+    cfg_off = O.RenderCfg(samples=32, scale=2)
+    assert float((emb(x.to(dev).reshape(7, 111, 3), 0.5).cpu().reshape(777, 63) - O.embed(x, 0.5, cfg_off)).abs().max()) < 2e-6
+    x_enc = O.embed(x, 0.5, cfg_off)
+    for typ, nc, seed in (("coarse", cfg.coarse, 5), ("fine", cfg.fine, 6)):
+        net = CorseFine_NeRF(sp, type=typ).to(dev)
+        p = O.init_params(nc, seed)
+        net.load_state_dict(p)
+        out = net(x_enc.to(dev), dirs.to(dev))
+        ref = O.mlp_forward(p, nc, x_enc, dirs)
+        assert out.shape == (777, 4) and float((out.cpu() - ref).abs().max()) < 2e-5
