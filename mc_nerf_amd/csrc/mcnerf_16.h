@@ -242,6 +242,12 @@ __device__ __forceinline__ void mcn16_dma16(const char* gsrc, unsigned lds_dst) 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// the same with the non-temporal cache policy: for operands that are read exactly once (the weight-gradient streams)
+__device__ __forceinline__ void mcn16_dma16_nt(const char* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 // 256-byte piece: one dword per lane (LDS destination = lds_dst + lane * 4)
 __device__ __forceinline__ void mcn16_dma4(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
