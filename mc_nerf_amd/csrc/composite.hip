@@ -31,6 +31,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Running maximum of non-negative floats (as bit patterns) in ONE device word.  Every ray's wave contributes, and tens of
+// thousands of same-address atomics serialise in the L2 (~150 us per launch at 32768 rays): read the word first with an
+// L1-bypassing load and skip the atomic unless this wave would raise it -- after the first few waves almost none does.
+// (A stale, lower value only costs a redundant atomic; the maximum never decreases.)
+__device__ __forceinline__ void running_max_bits(unsigned* word, float v) {
+    const unsigned mine = __float_as_uint(v);
+    if (mine > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, mine);
+}
+
 __global__ __launch_bounds__(256) void composite_fwd_kernel(McnCompositeArgs a) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(McnCompositeArgs a) 
     if (a.depth) { aop = wave_sum(aop); adep = wave_sum(adep); }
     if (a.eps_sel && a.wmax_bits) {
         wmx = wave_max(wmx);
-        if (lane == 0) atomicMax(a.wmax_bits, __float_as_uint(wmx));
+        if (lane == 0) running_max_bits(a.wmax_bits, wmx);
     }
     if (lane == 0) {
         if (a.white_back) { ar = (ar + 1.f) - aw; ag = (ag + 1.f) - aw; ab = (ab + 1.f) - aw; }
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(McnCompositeBwdArgs 
     }
     if (a.gmax_bits) {
         gmx = wave_max(gmx);
-        if (lane == 0 && gmx < 3e38f) atomicMax(a.gmax_bits, __float_as_uint(gmx));
+        if (lane == 0 && gmx < 3e38f) running_max_bits(a.gmax_bits, gmx);
     }
 }
 
