@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
         // Issue points are at least two segments ahead, so the counted ring waits in between cover their landing
         // (W >= 128); the narrow test nets drain explicitly.
         // Narrower nets (short layers: the drain is cheap, the extra DMA instructions are not: measured 0.75 vs 0.83 ms on
-        // the 4x128 net) read them with ordinary loads at the point of use.
+        // the 4x128 net) use ordinary loads into a register set (`mpend`) one layer ahead of their use.
         constexpr bool MASK_DMA = W >= 256;
         const unsigned mlds = ring.lds_base + SM::oMask + wave * (3 * MW * 256);
         auto mask_issue = [&](int slot, int buf) {
@@ -198,8 +198,11 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
             mcn16_ws_store(dshf[1], reinterpret_cast<u32x4_t*>(e + 1024));
         }
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the prologue's loads and the first three mask buffers have landed
-        mask_read(mk_s, 0, D);
+        if (!MASK_DMA) { mask_read(mk_s, 0, D); mask_read(mk_c, 1, D + 1); mask_read(mk_t, 2, D - 1); }     // (with the prologue's other loads)
+        if (MASK_DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the prologue's loads and the first three mask buffers have landed
+            mask_read(mk_s, 0, D);
+        }
         u32x4_t xa[KS], xb[KS];
         f32x16 denc[2];
         u32x4_t dencp[4];            // the skip layer's share of the encoded-input gradient, parked in 16 bit until layer 0
@@ -220,22 +223,30 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
         }
         // ---- sigma.0^T (partial, 16 bit) ; sh.2^T -> dY of sh.0 ; sh.0^T + partial -> dY_{D-1}
         if (D >= 2) mask_issue(D - 2, buf_of(D - 2));          // buffer 0 is free (the sigma path is done)
+        unsigned mpend[MW];
+        if (!MASK_DMA && D >= 2) mask_read(mpend, 0, D - 2);
         mcn16_bwd_seg<W, BF, KS, NT, 0>(ring, smem, lane, xa, xb, mk_s, denc, nullptr);
-        mask_read(mk_c, 1, D + 1);
+        if (MASK_DMA) mask_read(mk_c, 1, D + 1);
         {
             u32x4_t dsh_in[KS];
             dsh_in[0] = dshf[0]; dsh_in[1] = dshf[1];
             mcn16_bwd_seg<W, BF, 2, NT, 1>(ring, smem, lane, dsh_in, xa, mk_c, denc, dy_lane + (size_t)(D + 1) * a.slot_bytes);
         }
         if (D >= 3) mask_issue(D - 3, buf_of(D - 3));          // buffer 1 is free (sh.2^T is done)
-        mask_read(mk_t, 2, D - 1);
+        if (MASK_DMA) mask_read(mk_t, 2, D - 1);
         mcn16_bwd_seg<W, BF, KS, NT, 2>(ring, smem, lane, xa, xb, mk_t, denc, dy_lane + (size_t)(D - 1) * a.slot_bytes);
         // ---- trunk, last layer to first: xb = dY_l
         for (int l = D - 1; l >= 1; --l) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) xa[s] = xb[s];
-            if (l >= 3) mask_issue(l - 3, buf_of(l - 3));      // the buffer of slot l (previous segment) is free
-            mask_read(mk_t, buf_of(l - 1), l - 1);
+            if (MASK_DMA) {
+                if (l >= 3) mask_issue(l - 3, buf_of(l - 3));  // the buffer of slot l (previous segment) is free
+                mask_read(mk_t, buf_of(l - 1), l - 1);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MW; ++i) mk_t[i] = mpend[i];
+                if (l >= 2) mask_read(mpend, 0, l - 2);
+            }
             if (l == skip) mcn16_bwd_seg<W, BF, KS, 2, 0, 4>(ring, smem, lane, xa, dencp, mk_t, denc, nullptr);
             mcn16_bwd_seg<W, BF, KS, NT, 1>(ring, smem, lane, xa, xb, mk_t, denc, dy_lane + (size_t)(l - 1) * a.slot_bytes);
         }
