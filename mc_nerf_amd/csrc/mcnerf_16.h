@@ -22,11 +22,14 @@
 #pragma once
 #include "mcnerf_common.h"
 
-#define MCN16_SLAB 16                 // fragments (1 KiB each) per ring slab
-#define MCN16_RING 8                  // slabs in the LDS ring (128 KiB)
-#ifndef MCN16_AHEAD
-#define MCN16_AHEAD 6                 // slabs in flight ahead of the one being consumed (RING >= AHEAD + 1)
+#ifndef MCN16_SLAB
+#define MCN16_SLAB 16                 // fragments (1 KiB each) per ring slab (a multiple of 8: every wave issues SLAB / 8 pieces)
 #endif
+#define MCN16_RING (128 / MCN16_SLAB) // slabs in the LDS ring (128 KiB; a power of two)
+#ifndef MCN16_AHEAD
+#define MCN16_AHEAD (MCN16_RING - 2)  // slabs in flight ahead of the one being consumed (early sync: RING >= AHEAD + 2)
+#endif
+#define MCN16_PPW (MCN16_SLAB / 8)    // LDS-DMA pieces per wave and slab
 #define MCN16_WAVES 8
 #define MCN16_ROWS (32 * MCN16_WAVES) // rows per workgroup pass
 #define MCN16_ENCKS 4                 // k-steps of the 64 (63 + pad) encoded channels
@@ -221,7 +224,7 @@ __device__ __forceinline__ void mcn16_ws_store(const V& v, V* p) {
 // refilled at that point belongs to a slab every wave has already left.
 #define MCN16_PF 4
 struct Mcn16Ring {
-    const char* src;          // packed stream + this lane's byte offset inside a slab (piece 2 * wave, lane * 16)
+    const char* src;          // packed stream + this lane's byte offset inside a slab (piece PPW * wave, lane * 16)
     unsigned lds_piece;       // LDS byte offset of this wave's first piece inside a slab (wave-uniform)
     unsigned lds_base;        // LDS address of the ring
     int src_slab;             // stream slab that the next issue fetches (wraps at n_slabs)
@@ -257,8 +260,8 @@ __device__ __forceinline__ void mcn16_dma4(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void mcn16_ring_issue(Mcn16Ring& r, char* ring_lds) {
     const char* s = r.src + (size_t)r.src_slab * (MCN16_SLAB * 1024);
     const unsigned d = r.lds_base + r.issue_slot * (MCN16_SLAB * 1024) + r.lds_piece;
-    mcn16_dma16(s, d);
-    mcn16_dma16(s + 1024, d + 1024);
+#pragma unroll
+    for (int i = 0; i < MCN16_PPW; ++i) mcn16_dma16(s + i * 1024, d + i * 1024);
     r.src_slab = (r.src_slab + 1 == r.n_slabs) ? 0 : r.src_slab + 1;
     r.issue_slot = (r.issue_slot + 1) & (MCN16_RING - 1);
 }
@@ -268,15 +271,15 @@ __device__ __forceinline__ void mcn16_ring_sync(Mcn16Ring& r, char* ring_lds) {
 #ifdef MCN16_EXP_VMCNT      // (timing experiment only: a larger count is NOT safe in general)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MCN16_EXP_VMCNT) : "memory");
 #else
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (MCN16_AHEAD - 1)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MCN16_PPW * (MCN16_AHEAD - 1)) : "memory");
 #endif
     r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
     r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
     mcn16_ring_issue(r, ring_lds);
 }
 __device__ __forceinline__ void mcn16_ring_start(Mcn16Ring& r, char* ring_lds, const void* packed, int n_slabs, int wave, int lane) {
-    r.src = reinterpret_cast<const char*>(packed) + (2 * wave) * 1024 + lane * 16;
-    r.lds_piece = (2 * wave) * 1024;
+    r.src = reinterpret_cast<const char*>(packed) + (MCN16_PPW * wave) * 1024 + lane * 16;
+    r.lds_piece = (MCN16_PPW * wave) * 1024;
     r.lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)ring_lds);
     r.src_slab = 0; r.n_slabs = n_slabs; r.issue_slot = 0; r.sync_slot = 0; r.next_off = 0;
 #pragma unroll
@@ -293,7 +296,7 @@ __device__ __forceinline__ void mcn16_before_mfma(Mcn16Ring& r, char* ring_lds, 
     // (f is a compile-time constant at every call site after unrolling)
     if ((f & (MCN16_SLAB - 1)) == 0) c.cur = r.next_off;
     const int q = f / MCN16_SLAB;
-    const int sync_at = (16 * q + 16 - MCN16_PF) < (F - 1) ? (16 * q + 16 - MCN16_PF) : (F - 1);
+    const int sync_at = (MCN16_SLAB * q + MCN16_SLAB - MCN16_PF) < (F - 1) ? (MCN16_SLAB * q + MCN16_SLAB - MCN16_PF) : (F - 1);
     if (f == sync_at) mcn16_ring_sync(r, ring_lds);
 }
 // LDS byte offset of fragment f (which may lie in the slab after the one being consumed: allowed once f's slab is synced)

@@ -98,7 +98,9 @@ __device__ __forceinline__ void mcn16_layer(Mcn16Ring& ring, char* smem, int lan
         if (i < 8) {
             const unsigned w = T::relu_pack(a[2 * i], a[2 * i + 1]);
             if (i < 4) o0[i] = w; else o1[i - 4] = w;
+#ifndef ABL16_NOMASK
             if (SAVE) mb = (i == 0) ? mcn16_nz(w) : ((mb << 1) | mcn16_nz(w));
+#endif
             if (EPI == 1) {
                 // (a float vector, not bit-cast integers: hipcc 7.2 folds fmaf((float)half, bit_cast<float>(u32x2[1]), acc) into a
                 //  v_fma_mix_f32 that reads element 0 again)
@@ -112,8 +114,14 @@ __device__ __forceinline__ void mcn16_layer(Mcn16Ring& ring, char* smem, int lan
                 if (SAVE) mw[t >> 1] |= mb << (8 * (t & 1));
             }
         } else if (SAVE) {
+#ifdef ABL16_NOSTORE      // (timing-only ablation: the stores are compiled but never executed)
+            if (reinterpret_cast<size_t>(mask_lane) == 1) {
+#endif
             if (i == 8) mcn16_ws_store(o0, reinterpret_cast<u32x4_t*>(save_lane + (2 * t) * 1024));
             else mcn16_ws_store(o1, reinterpret_cast<u32x4_t*>(save_lane + (2 * t + 1) * 1024));
+#ifdef ABL16_NOSTORE
+            }
+#endif
         }
     };
     cur.cur = ring.next_off;
@@ -233,8 +241,10 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
         mcn16_layer<W, BF, SAVE, 0, KS, 1>(ring, smem, lane, encf, xb, xa, bias_h + D * W, w2_h, dot,
                                            SAVE ? act_lane + (size_t)D * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)D * a.mask_slot_words : nullptr);
         // ---- SH head: hidden layer (reads the same trunk output), then the 27 (32) coefficient rows
+#ifndef ABL16_NOSHHIDDEN   // (timing-only ablation: one 128-MFMA layer body less in the instruction stream)
         mcn16_layer<W, BF, SAVE, 0, KS, 0>(ring, smem, lane, encf, xb, xa, bias_h + (D + 1) * W, nullptr, dot,
                                            SAVE ? act_lane + (size_t)(D + 1) * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)(D + 1) * a.mask_slot_words : nullptr);
+#endif
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
