@@ -3,8 +3,13 @@
 // over the fragment-major 16-bit workspaces written by mlp16_fwd.hip (X) and mlp16_bwd.hip (dY, scaled by SG).
 // Replaces the dW half of autograd's addmm backward for every nn.Linear of CorseFine_NeRF (model/net_block.py:51-65).
 //
-// HBM-bound streaming kernel: persistent, one workgroup (8 waves) per CU takes a contiguous run of 32-row tiles, keeps
-// its whole dW block in MFMA accumulators and adds it with one fp32 float-atomic pass at the end.  A 32-row tile of both
+// HBM-bound streaming kernel, ONE launch per net: the 13 (depth + 5) GEMM segments of a net are laid end to end as one
+// linear sequence of 32-row tiles weighted by their bytes, the sequence is cut into gridDim.x equal pieces and the
+// persistent workgroup (8 waves, one per CU) b streams piece b.  A piece lies inside one segment or crosses one
+// boundary, so a segment's dW block is flushed (fp32 float atomics from the MFMA accumulators) by ~ grid / 13 + 1
+// workgroups instead of by all of them: the flush (16.8 M lane-atomics per 256x256 block and workgroup round, measured
+// 58 us per segment when every workgroup flushed every segment) drops by 12x and overlaps the other workgroups'
+// streaming.  A 32-row tile of both
 // operands ((N + K) / 16 fragments of 1 KiB) is one stage of a 4-stage LDS ring filled by LDS-DMA (inline asm, counted
 // vmcnt, one raw barrier per tile).  The contraction runs over SAMPLES, which sit on the lanes of the saved fragments,
 // so both MFMA operands are read with ds_read_b64_tr_b16 (the transposing LDS read): a fragment's 16-byte chunks are
@@ -38,8 +43,10 @@ constexpr int dw16_pick(int N, int K, bool want_vn) {
 #define DW16_STAGES 4
 #endif
 
+// tiles [t0, t1) of one segment: stream, accumulate, flush.  Leaves no LDS-DMA piece outstanding and every wave past the
+// barrier that follows the last LDS read, so the next segment's run may refill the ring at once.
 template <int N, int K, bool BF>
-__global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_kernel(Dw16Seg sg, const int* count, int rows_cap, const unsigned* gmax_bits) {
+__device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const int t1, const float sgs, char* smem) {
     using T = Mcn16T<BF>;
     constexpr int KSN = N / 16, KSK = K / 16, P = KSN + KSK;          // 1 KiB pieces per tile
     constexpr int PW = (P + MCN16_WAVES - 1) / MCN16_WAVES;           // pieces per wave (the trailing waves may issue PW - 1)
@@ -47,21 +54,12 @@ __global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_kernel(Dw16Seg sg, cons
     constexpr int NG = N / (32 * VN), KG = K / (32 * KT), G = NG * KG, MS = MCN16_WAVES / G;
     static_assert(G >= 1 && MCN16_WAVES % G == 0, "wave tiling");
     constexpr int STAGE = P * 1024;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
 
-    const int rows = count ? min(*count, rows_cap) : rows_cap;
-    const int ntiles = (rows + 31) / 32;
-    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int t0 = blockIdx.x * per;
-    if (t0 >= ntiles) return;
-    const int t1 = min(t0 + per, ntiles);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gi = wave % G, ms = wave / G;
     const int nbase = (gi % NG) * 32 * VN, kbase = (gi / NG) * 32 * KT;
-    const float gmax = gmax_bits ? __uint_as_float(*gmax_bits) : 1.f;
-    const float sgs = (gmax > 0.f && gmax < 3e38f) ? exp2f(4.f - ceilf(log2f(gmax))) : 1.f;
 
     // ---- LDS-DMA pieces of this wave: piece pi = wave + 8 i (dY fragments first, then X fragments)
     const unsigned lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem);
@@ -186,7 +184,13 @@ __global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_kernel(Dw16Seg sg, cons
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+#if defined(DW16_ABL_NOEPI)       // (timing-only ablations of the accumulator flush)
+                if (n >= sg.n_lo && n < sg.n_real && k < sg.k_real && acc[t][kt][e] == 12345.f) sg.dW[k] = 0.f;
+#elif defined(DW16_ABL_WGSCOPE)
+                if (n >= sg.n_lo && n < sg.n_real && k < sg.k_real) __hip_atomic_fetch_add(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + k, acc[t][kt][e] * inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
                 if (n >= sg.n_lo && n < sg.n_real && k < sg.k_real) atomicAdd(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + k, acc[t][kt][e] * inv);
+#endif
             }
         }
     if (bias) {
@@ -196,6 +200,41 @@ __global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_kernel(Dw16Seg sg, cons
             const int n = nbase + 32 * t + r;
             if (h == 0 && n >= sg.n_lo && n < sg.n_real) atomicAdd(sg.db + (n - sg.n_lo), b);
         }
+    }
+}
+
+// ---- one launch per net ---------------------------------------------------------------------------------------------
+#define DW16_MAXSEG 15
+struct Dw16Job {
+    int n;
+    int shape[DW16_MAXSEG];       // 0: W x W   1: W x 64 (encoded-input columns)   2: 32 x W (sh.2 / sigma.2 rows)
+    Dw16Seg seg[DW16_MAXSEG];
+};
+
+template <int W, bool BF>
+__global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_stream_kernel(Dw16Job job, const int* count, int rows_cap, const unsigned* gmax_bits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rows = count ? min(*count, rows_cap) : rows_cap;
+    const int ntiles = (rows + 31) / 32;
+    if (ntiles <= 0) return;
+    const float gmax = gmax_bits ? __uint_as_float(*gmax_bits) : 1.f;
+    const float sgs = (gmax > 0.f && gmax < 3e38f) ? exp2f(4.f - ceilf(log2f(gmax))) : 1.f;
+    // the linear tile sequence, in units of 1 KiB pieces: segment s holds ntiles tiles of pieces(shape) each
+    auto pieces = [](int shape) { return shape == 0 ? 2 * W / 16 : shape == 1 ? W / 16 + MCN16_ENCKS : 2 + W / 16; };
+    long long total = 0;
+    for (int s = 0; s < job.n; ++s) total += (long long)pieces(job.shape[s]) * ntiles;
+    const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
+    long long base = 0;
+    for (int s = 0; s < job.n; ++s) {
+        const int shape = job.shape[s], P = pieces(shape);
+        // a tile belongs to the piece that holds its first 1 KiB piece
+        const long long a = (lo - base + P - 1) / P, e = (hi - base + P - 1) / P;
+        const int t0 = (int)(a < 0 ? 0 : a > ntiles ? ntiles : a), t1 = (int)(e < 0 ? 0 : e > ntiles ? ntiles : e);
+        base += (long long)P * ntiles;
+        if (t0 >= t1) continue;                                        // (block-uniform)
+        if (shape == 0) dw16_run<W, W, BF>(job.seg[s], t0, t1, sgs, smem);
+        else if (shape == 1) dw16_run<W, 16 * MCN16_ENCKS, BF>(job.seg[s], t0, t1, sgs, smem);
+        else dw16_run<32, W, BF>(job.seg[s], t0, t1, sgs, smem);
     }
 }
 
@@ -210,31 +249,23 @@ static int dw16_num_cus() {
     return cus;
 }
 
-template <int N, int K>
-static hipError_t dw16_launch_t(const Dw16Seg& s, const int* count, int rows_cap, int bf16, const unsigned* gmax_bits, hipStream_t st) {
-    const int ntiles = (rows_cap + 31) / 32;
-    int grid = dw16_num_cus();
-    if (grid > ntiles) grid = ntiles;
-    const size_t lds = (size_t)DW16_STAGES * (N + K) / 16 * 1024;
-    void (*kern)(Dw16Seg, const int*, int, const unsigned*) = bf16 ? dw16_kernel<N, K, true> : dw16_kernel<N, K, false>;
-    if (lds > 64 * 1024) {
+template <int W>
+static hipError_t dw16_launch_job(const Dw16Job& job, const int* count, int rows_cap, int bf16, const unsigned* gmax_bits, hipStream_t st) {
+    if (rows_cap <= 0) return hipSuccess;
+    const long long ntiles = (rows_cap + 31) / 32;
+    long long grid = dw16_num_cus();
+    if (grid > ntiles * job.n) grid = ntiles * job.n;
+    const int pmax = 2 * W / 16 > W / 16 + MCN16_ENCKS ? 2 * W / 16 : W / 16 + MCN16_ENCKS;
+    const size_t lds = (size_t)DW16_STAGES * pmax * 1024;
+    void (*kern)(Dw16Job, const int*, int, const unsigned*) = bf16 ? dw16_stream_kernel<W, true> : dw16_stream_kernel<W, false>;
+    static bool attr_set[2] = {false, false};                          // (per width instantiation and precision)
+    if (lds > 64 * 1024 && !attr_set[bf16 ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        attr_set[bf16 ? 1 : 0] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * MCN16_WAVES), lds, st, s, count, rows_cap, gmax_bits);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MCN16_WAVES), lds, st, job, count, rows_cap, gmax_bits);
     return hipGetLastError();
-}
-
-static hipError_t dw16_launch(const Dw16Seg& s, const int* count, int rows_cap, int bf16, const unsigned* gmax_bits, hipStream_t st) {
-    if (rows_cap <= 0) return hipSuccess;
-#define DW16_CASE(NN, KK) case NN * 1000 + KK: return dw16_launch_t<NN, KK>(s, count, rows_cap, bf16, gmax_bits, st)
-    switch (s.ksn * 16 * 1000 + s.ksk * 16) {
-        DW16_CASE(256, 256); DW16_CASE(256, 64); DW16_CASE(32, 256);
-        DW16_CASE(128, 128); DW16_CASE(128, 64); DW16_CASE(32, 128);
-        DW16_CASE(64, 64); DW16_CASE(32, 64); DW16_CASE(32, 32);
-        default: return hipErrorInvalidValue;
-    }
-#undef DW16_CASE
 }
 
 hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
@@ -244,26 +275,28 @@ hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
     auto dy = [&](int slot) { return reinterpret_cast<const char*>(a.dy_ws) + (size_t)slot * a.slot_bytes; };
     const char* enc = reinterpret_cast<const char*>(a.enc_ws);
     const char* dsh = reinterpret_cast<const char*>(a.dsh_ws);
-    hipError_t e;
+    Dw16Job job;
+    job.n = 0;
+    auto add = [&](int shape, const Dw16Seg& s) { job.shape[job.n] = shape; job.seg[job.n] = s; ++job.n; };
+    if (D + 5 > DW16_MAXSEG) return hipErrorInvalidValue;
     for (int l = 0; l < D; ++l) {
         const int ldw = mcn_in_features(D, W, L.skip, l);
-        if (l == 0 || l == L.skip) {      // encoded-input columns
-            Dw16Seg s = {dy(l), KS, enc, MCN16_ENCKS, 0, W, MCN_ENC, a.grads + L.pW[l], ldw, a.grads + L.pB[l]};
-            if ((e = dw16_launch(s, a.count, a.rows, a.bf16, a.gmax_bits, st)) != hipSuccess) return e;
-        }
-        if (l > 0) {                      // hidden-input columns (after the 63 encoded ones at the skip layer)
-            Dw16Seg s = {dy(l), KS, act(l - 1), KS, 0, W, W, a.grads + L.pW[l] + (l == L.skip ? MCN_ENC : 0), ldw,
-                         l == L.skip ? nullptr : a.grads + L.pB[l]};
-            if ((e = dw16_launch(s, a.count, a.rows, a.bf16, a.gmax_bits, st)) != hipSuccess) return e;
-        }
+        if (l == 0 || l == L.skip)        // encoded-input columns
+            add(1, Dw16Seg{dy(l), KS, enc, MCN16_ENCKS, 0, W, MCN_ENC, a.grads + L.pW[l], ldw, a.grads + L.pB[l]});
+        if (l > 0)                        // hidden-input columns (after the 63 encoded ones at the skip layer)
+            add(0, Dw16Seg{dy(l), KS, act(l - 1), KS, 0, W, W, a.grads + L.pW[l] + (l == L.skip ? MCN_ENC : 0), ldw,
+                           l == L.skip ? nullptr : a.grads + L.pB[l]});
     }
-    Dw16Seg s1 = {dy(D), KS, act(D - 1), KS, 0, W, W, a.grads + L.pWs1, W, a.grads + L.pBs1};
-    if ((e = dw16_launch(s1, a.count, a.rows, a.bf16, a.gmax_bits, st)) != hipSuccess) return e;
-    Dw16Seg c1 = {dy(D + 1), KS, act(D - 1), KS, 0, W, W, a.grads + L.pWc1, W, a.grads + L.pBc1};
-    if ((e = dw16_launch(c1, a.count, a.rows, a.bf16, a.gmax_bits, st)) != hipSuccess) return e;
-    Dw16Seg c2 = {dsh, 2, act(D + 1), KS, 0, MCN_NSH, W, a.grads + L.pWc2, W, a.grads + L.pBc2};
-    if ((e = dw16_launch(c2, a.count, a.rows, a.bf16, a.gmax_bits, st)) != hipSuccess) return e;
+    add(0, Dw16Seg{dy(D), KS, act(D - 1), KS, 0, W, W, a.grads + L.pWs1, W, a.grads + L.pBs1});
+    add(0, Dw16Seg{dy(D + 1), KS, act(D - 1), KS, 0, W, W, a.grads + L.pWc1, W, a.grads + L.pBc1});
+    add(2, Dw16Seg{dsh, 2, act(D + 1), KS, 0, MCN_NSH, W, a.grads + L.pWc2, W, a.grads + L.pBc2});
     // sigma.2 (1 x W): d sigma sits in column 27 of dsh, its input is the sigma hidden layer
-    Dw16Seg s2 = {dsh, 2, act(D), KS, MCN_NSH, MCN_NSH + 1, W, a.grads + L.pWs2, W, a.grads + L.pBs2};
-    return dw16_launch(s2, a.count, a.rows, a.bf16, a.gmax_bits, st);
+    add(2, Dw16Seg{dsh, 2, act(D), KS, MCN_NSH, MCN_NSH + 1, W, a.grads + L.pWs2, W, a.grads + L.pBs2});
+    switch (W) {
+        case 256: return dw16_launch_job<256>(job, a.count, a.rows, a.bf16, a.gmax_bits, st);
+        case 128: return dw16_launch_job<128>(job, a.count, a.rows, a.bf16, a.gmax_bits, st);
+        case 64:  return dw16_launch_job<64>(job, a.count, a.rows, a.bf16, a.gmax_bits, st);
+        case 32:  return dw16_launch_job<32>(job, a.count, a.rows, a.bf16, a.gmax_bits, st);
+        default:  return hipErrorInvalidValue;
+    }
 }

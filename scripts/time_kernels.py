@@ -33,6 +33,14 @@ fns = {
     "bwd": lambda: ops.mlp_bwd(net, flat, packed, o, d, zg, None, bw, out, d_out, save, dy, dsh, d_o, d_d, precision=prec, gmax=gmax),
     "dw": lambda: ops.mlp_dw(net, save, dy, dsh, grads, N * S, precision=prec, gmax=gmax),
 }
+# optional shader-clock probe (scripts/dbg/libclockprobe.so): a one-wave kernel on a side stream samples s_memtime against the
+# 100 MHz counter every 50 us while the timed kernel runs -> effective MHz under that kernel's load
+probe = None
+if os.environ.get("CLOCKPROBE"):
+    import ctypes
+    probe = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "dbg", "libclockprobe.so"))
+    probe.clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]
+    side = torch.cuda.Stream()
 res = []
 which = sys.argv[4].split(",") if len(sys.argv) > 4 else list(fns)
 flop = 2.0 * sum(a * b for (a, b) in [sh for sh in net.shapes() if len(sh) == 2]) * N * S
@@ -42,9 +50,20 @@ for name, fn in fns.items():
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 4
+    if probe is not None:
+        ns = 200
+        buf = torch.zeros(2 * ns, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        probe.clock_probe(buf.data_ptr(), ns, 5000, side.cuda_stream)      # 200 samples x 50 us = 10 ms
+        reps = 8
     e0.record()
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    res.append(f"{name} {ms:7.2f} ms ({flop / ms * 1e-9:6.1f} TF)")
+    clk = ""
+    if probe is not None:
+        b = buf.cpu().view(ns, 2).double()
+        mhz = b[:, 0] / b[:, 1] * 100.0
+        clk = f" clk {mhz[20:].mean():.0f} MHz (min {mhz[20:].min():.0f} max {mhz[20:].max():.0f})"
+    res.append(f"{name} {ms:7.2f} ms ({flop / ms * 1e-9:6.1f} TF){clk}")
 print(os.environ.get("MCNERF_LIB", "default"), prec, f"rows={N * S}", " | ".join(res), "finite", bool(torch.isfinite(out).all()))
