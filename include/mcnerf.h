@@ -87,6 +87,12 @@ int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const fl
  *   mcnerf_encode   = SinCosEmbedding.forward (:20-35): x [n,3], barf_w [10] -> out [n,63];
  *   mcnerf_mlp_apply = CorseFine_NeRF.forward (:67-78): x_enc [n,63], dirs [n,3] -> out [n,4] = (sigma_raw, r, g, b). */
 int mcnerf_encode(const float* x, const float* barf_w, int n, float* out, void* stream);
+
+/* Stream-ordered upload of up to 16 host floats WITHOUT a host-device copy: the values travel as kernel arguments and a
+ * one-wave kernel stores them to `dst` (device).  For the per-step host scalars of the train step (the ten BARF weights of
+ * model/net_block.py:26-29, evaluated in fp32 on the host exactly as the reference does): a pageable hipMemcpy would block
+ * the host until every kernel queued before it has finished, i.e. serialise host and device once per step. */
+int mcnerf_upload_f32(float* dst, const float* host_vals, int n, void* stream);
 int mcnerf_mlp_apply(int depth, int width, int skip, const float* params, const float* packed, const float* x_enc,
                      const float* dirs, int n, float* out, void* stream);
 

@@ -98,6 +98,11 @@ int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const fl
     return check("mcnerf_mlp_fwd", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
 }
 
+int mcnerf_upload_f32(float* dst, const float* host_vals, int n, void* stream) {
+    REQ(dst && host_vals && n >= 0 && n <= 16, "mcnerf_upload_f32");
+    return check("mcnerf_upload_f32", mcn_launch_upload_f32(dst, host_vals, n, (hipStream_t)stream));
+}
+
 int mcnerf_encode(const float* x, const float* barf_w, int n, float* out, void* stream) {
     REQ(x && barf_w && out && n >= 0, "mcnerf_encode");
     return check("mcnerf_encode", mcn_launch_encode(x, barf_w, n, out, (hipStream_t)stream));

@@ -210,6 +210,8 @@ template <class V>
 __device__ __forceinline__ void mcn16_ws_store(const V& v, V* p) {
 #if defined(ABL16_PLAINSTORE)
     *p = v;
+#elif defined(ABL16_SINKSTORE)      // (timing only: the value is computed, the store is not issued)
+    asm volatile("" ::"v"(v), "v"(p));
 #else
     __builtin_nontemporal_store(v, p);
 #endif

@@ -217,6 +217,18 @@ hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, float* 
     return hipGetLastError();
 }
 
+// up to 16 host floats by value (kernel arguments) -> device memory: a stream-ordered upload that never blocks the host
+struct McnFloats16 { float v[16]; };
+__global__ void upload_f32_kernel(float* dst, McnFloats16 vals, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+hipError_t mcn_launch_upload_f32(float* dst, const float* host_vals, int n, hipStream_t st) {
+    McnFloats16 v = {};
+    for (int i = 0; i < n && i < 16; ++i) v.v[i] = host_vals[i];
+    hipLaunchKernelGGL(upload_f32_kernel, dim3(1), dim3(64), 0, st, dst, v, n);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ ray generation
 // d = normalize(R^T K^-1 [u+.5, v+.5, 1]^T), o = -R^T t, following the reference's op order
 // (pix @ K^-T, lift, @ pose_inv^T, minus origin, normalise) so results agree to ~1e-7.

@@ -163,7 +163,7 @@ class NeRF_Model(nn.Module):
         st = self.settings
         flat = model.flat_params()
         packed = ops.pack_weights(model.net, flat, precision=st.precision)
-        barf_w = embedding_xyz.barf_weights(step_r).to(dev)
+        barf_w = embedding_xyz.barf_weights_on(step_r, dev)
         if idx_render is None:
             out = torch.empty(N, S_, 4, dtype=torch.float32, device=dev)
             ops.mlp_fwd(model.net, flat, packed, rays_o, rays_d, grid, jitter, barf_w, out, precision=st.precision)
@@ -298,8 +298,10 @@ class MC_Model(nn.Module):
         self.batch = sys_param["batch"]
         self.intr = sys_param["intr_mat"]
         self.intr_inv = sys_param["intr_mat_inv"]
-        self.intr_train, self.intr_test, self.intr_val = self.intr
-        self.intr_train_inv, self.intr_test_inv, self.intr_val_inv = self.intr_inv
+        # the constant intrinsics live on the device from the start (a per-step .to(device) of a host tensor is a
+        # synchronous copy: it would stall the host behind every queued kernel)
+        self.intr_train, self.intr_test, self.intr_val = [t.to(self.device) for t in self.intr]
+        self.intr_train_inv, self.intr_test_inv, self.intr_val_inv = [t.to(self.device) for t in self.intr_inv]
         self.gt_pose = sys_param["gt_pose"].to(self.device)
         self.test_pose = sys_param["test_pose"].to(self.device)
         self.valid_pose = sys_param["valid_pose"].to(self.device)
@@ -332,8 +334,9 @@ class MC_Model(nn.Module):
     def _forward_train(self, data, epoch, epoch_type, cur_ratio):
         cam = int(data[1].reshape(-1)[0])          # read the camera id on the host side, before the H2D copy
         images = data[0] if isinstance(data[0], DeviceImageSet) else None      # device-resident uint8 images (row f3)
-        gt_rgbs, img_id, intr_wpts, intr_pts, extr_wpts, extr_pts = [
-            t if isinstance(t, DeviceImageSet) else t.to(self.device) for t in data]
+        # (the image index stays on the host: it is only ever used as a python index)
+        gt_rgbs, _, intr_wpts, intr_pts, extr_wpts, extr_pts = [
+            t if isinstance(t, DeviceImageSet) or i == 1 else t.to(self.device) for i, t in enumerate(data)]
         loss_dict = {}
         emb = self.nerf.emmbedding_xyz
         if epoch_type == "CAM_PARAM_EPOCH":
@@ -358,9 +361,9 @@ class MC_Model(nn.Module):
             self.opt_idx = 1 if joint else 2
         # validation rays of the same index, every step, as the reference (:97-99)
         with torch.no_grad():
-            rays_dv, rays_ov = self.get_rays(self.valid_pose, cam, self.intr_val_inv.to(self.device))
-            rays_valid = [rays_dv, rays_ov, self.valid_rgbs[img_id].detach()]
-        intr_show = [self.intr_train.to(self.device).detach(), self.intr_adj.detach()]
+            rays_dv, rays_ov = self.get_rays(self.valid_pose, cam, self.intr_val_inv)
+            rays_valid = [rays_dv, rays_ov, self.valid_rgbs[cam:cam + 1].detach()]
+        intr_show = [self.intr_train.detach(), self.intr_adj.detach()]
         pose_show = [self.gt_pose.detach(), self.pose_adj.detach()]
         self.last_epoch_type = epoch_type
         return loss_dict, intr_show, pose_show, rays_valid
@@ -368,7 +371,7 @@ class MC_Model(nn.Module):
     @torch.no_grad()
     def render_image_device(self, img_id):
         """The demo render of one test camera (:106-122) with the result left on the device."""
-        rays_d, rays_o = self.get_rays(self.test_pose, img_id, self.intr_test_inv.to(self.device))
+        rays_d, rays_o = self.get_rays(self.test_pose, img_id, self.intr_test_inv)
         return self.nerf.render_chunked(rays_d, rays_o, self.nerf.nerf_coarse, self.nerf.nerf_fine, chunk=self.batch)
 
     @torch.no_grad()
@@ -381,8 +384,9 @@ class MC_Model(nn.Module):
         """All H*W rays of camera ``img_id`` (row-major pixel centres), differentiable wrt the
         selected pose and inverse intrinsics."""
         cam = int(torch.as_tensor(img_id).reshape(-1)[0])
-        pix = torch.arange(self.img_h * self.img_w, device=self.device)
-        return RaygenFn.apply(pose[cam].to(self.device), intr_inv[cam].to(self.device), pix, self.img_w)
+        if getattr(self, "_all_pix", None) is None:
+            self._all_pix = torch.arange(self.img_h * self.img_w, device=self.device)
+        return RaygenFn.apply(pose[cam].to(self.device), intr_inv[cam].to(self.device), self._all_pix, self.img_w)
 
     def generate_rand_rays(self, rays_d, rays_o, rand=True):
         if rand:

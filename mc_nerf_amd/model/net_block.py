@@ -50,12 +50,18 @@ class SinCosEmbedding(nn.Module):
         k = torch.arange(L, dtype=torch.float32)
         return (1.0 - torch.cos(torch.clamp(alpha - k, 0.0, 1.0) * math.pi)) / 2.0
 
+    def barf_weights_on(self, step_r, device) -> torch.Tensor:
+        """``barf_weights`` as a device tensor; on a GPU the ten host values are passed as kernel arguments
+        (``ops.upload_f32``) so the host never blocks on the stream."""
+        w = self.barf_weights(step_r)
+        return ops.upload_f32(w, device) if torch.device(device).type == "cuda" else w.to(device)
+
     @torch.no_grad()
     def forward(self, x, step_r):
         """Reference :20-35: [..., 3] -> [..., 63].  Stand-alone, forward-only call of the HIP encoding kernel (the render
         path computes the encoding inside the fused MLP kernels and differentiates it there)."""
         flat = x.reshape(-1, 3).float().contiguous()
-        out = ops.encode(flat, self.barf_weights(step_r).to(flat.device))
+        out = ops.encode(flat, self.barf_weights_on(step_r, flat.device))
         return out.reshape(*x.shape[:-1], self.out_channels)
 
 

@@ -78,7 +78,7 @@ class RenderTrainFn(torch.autograd.Function):
         rays_d = rays_d.contiguous()
         rays_o = rays_o.contiguous()
         need_grad = any(ctx.needs_input_grad)
-        barf_w = owner.emmbedding_xyz.barf_weights(step_r).to(dev)
+        barf_w = owner.emmbedding_xyz.barf_weights_on(step_r, dev)
         jit = jitter.reshape(-1).contiguous()
 
         # ---- coarse pass (dense [N,Sc] grid)
@@ -173,7 +173,7 @@ def render_test(owner, model_c, model_f, rays_d, rays_o, eps_c, eps_sel, eps_f):
     N = rays_d.shape[0]
     rays_d = rays_d.contiguous()
     rays_o = rays_o.contiguous()
-    barf_w = owner.emmbedding_xyz.barf_weights(1).to(dev)
+    barf_w = owner.emmbedding_xyz.barf_weights_on(1, dev)
     net_c, net_f = model_c.net, model_f.net
     flat_c, flat_f = model_c.flat_params(), model_f.flat_params()
     prec = st.precision

@@ -199,6 +199,16 @@ def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
               _p(save.mask, torch.int32) if save else None, _stream())
 
 
+def upload_f32(host_vals: Tensor, device) -> Tensor:
+    """A small fp32 host tensor (<= 16 values) as a fresh device tensor, stream-ordered and without a host-device copy
+    (the values travel as kernel arguments): the host never waits for the kernels already queued."""
+    hv = host_vals.detach().reshape(-1).float().contiguous()
+    assert hv.device.type == "cpu" and hv.numel() <= 16
+    out = torch.empty(hv.numel(), dtype=torch.float32, device=device)
+    _lib.call("mcnerf_upload_f32", _p(out), hv.data_ptr(), hv.numel(), _stream())
+    return out
+
+
 def encode(x: Tensor, barf_w: Tensor) -> Tensor:
     """SinCosEmbedding.forward (model/net_block.py:20-35): [n,3] -> [n,63]."""
     n = x.shape[0]
