@@ -208,6 +208,11 @@ long long mcnerf_cap_ws_words(void);
 int mcnerf_cap_random(const int32_t* idx_in, const int32_t* count, int max_rows, int keep, const uint32_t* seed,
                       uint32_t* ws, int32_t* idx_out, int32_t* count_out, void* stream);
 
+/* The pixel subset of a train step, randperm(H * W)[:batch] of model/mc_nerf.py:329, drawn on the device in one kernel:
+ * out[i] = P(i), i < batch, with P a pseudo-random permutation of [0, n) keyed by the device word *seed (batch <= n <= 2^31):
+ * distinct, uniformly distributed pixel ids in random order. */
+int mcnerf_sample_perm(int64_t* out, long long n, int batch, const uint32_t* seed, void* stream);
+
 /* Ground-truth colours of n pixels of ONE uint8 image resident in HBM:
  * image [H*W, channels] (channels 3 = RGB, 4 = RGBA composited on white as data/data_read.py:130-137),
  * pix [n] int64 -> out [n,3] fp32.  Replaces the per-step H2D image copy + gather (model/mc_nerf.py:379, 80). */

@@ -98,6 +98,11 @@ int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const fl
     return check("mcnerf_mlp_fwd", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
 }
 
+int mcnerf_sample_perm(int64_t* out, long long n, int batch, const uint32_t* seed, void* stream) {
+    REQ(out && seed && batch >= 0 && n >= batch && n <= (1ll << 31), "mcnerf_sample_perm");
+    return check("mcnerf_sample_perm", mcn_launch_sample_perm((long long*)out, n, batch, seed, (hipStream_t)stream));
+}
+
 int mcnerf_upload_f32(float* dst, const float* host_vals, int n, void* stream) {
     REQ(dst && host_vals && n >= 0 && n <= 16, "mcnerf_upload_f32");
     return check("mcnerf_upload_f32", mcn_launch_upload_f32(dst, host_vals, n, (hipStream_t)stream));

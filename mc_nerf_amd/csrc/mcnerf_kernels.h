@@ -24,6 +24,7 @@ struct McnMlpFwdArgs {
     const float* enc_in = nullptr;   // fp32 kernel only: caller-supplied encodings [rows][63] instead of the fused positional encoding
 };
 hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, float* out, hipStream_t st);
+hipError_t mcn_launch_sample_perm(long long* out, long long n, int batch, const unsigned* seed, hipStream_t st);
 hipError_t mcn_launch_upload_f32(float* dst, const float* host_vals, int n, hipStream_t st);
 hipError_t mcn_launch_mlp_fwd(const McnMlpFwdArgs& a, hipStream_t st);
 hipError_t mcn_launch_mlp_fwd_h(const McnMlpFwdArgs& a, hipStream_t st);     // split-f16 mode: a.packed = mcn_launch_pack_h output

@@ -353,7 +353,7 @@ class MC_Model(nn.Module):
             kinv = self.intr_inv_adj[cam] if self.intr_inv_adj is not None else \
                 self.inverse_intrinsic(self.intr_adj[cam:cam + 1])[0]
             # pixel subset first (same device randperm as :329), rays only for those pixels
-            rand_idx = torch.randperm(self.img_h * self.img_w, device=self.device)[: self.batch]
+            rand_idx = self.sample_pixels(self.img_h * self.img_w)
             rays_d, rays_o = RaygenFn.apply(self.pose_adj[cam], kinv, rand_idx, self.img_w)
             rgbs_c, rgbs_f = self.nerf(rays_d, rays_o, epoch, cur_ratio if joint else 1)
             gt = images.gather(cam, rand_idx) if images is not None else gt_rgbs.reshape(-1, 3)[rand_idx]
@@ -367,6 +367,14 @@ class MC_Model(nn.Module):
         pose_show = [self.gt_pose.detach(), self.pose_adj.detach()]
         self.last_epoch_type = epoch_type
         return loss_dict, intr_show, pose_show, rays_valid
+
+    def sample_pixels(self, npix):
+        """The step's pixel subset, randperm(npix)[:batch] of the reference (:329): on the GPU one kernel
+        (``ops.sample_perm``, keyed from torch's device generator); parity tests replace this method to inject the
+        reference's draw."""
+        if self.weights_pose.is_cuda:
+            return ops.sample_perm(npix, min(self.batch, npix), self.weights_pose.device)
+        return torch.randperm(npix, device=self.device)[: self.batch]
 
     @torch.no_grad()
     def render_image_device(self, img_id):

@@ -199,6 +199,16 @@ def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
               _p(save.mask, torch.int32) if save else None, _stream())
 
 
+def sample_perm(n: int, batch: int, device, seed: Optional[Tensor] = None) -> Tensor:
+    """randperm(n)[:batch] (model/mc_nerf.py:329) in one kernel: `batch` distinct uniformly random ids of [0, n) in random
+    order (int64); the key is a device word drawn from torch's device generator, so torch.manual_seed reproduces it."""
+    if seed is None:
+        seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int32, device=device)
+    out = torch.empty(batch, dtype=torch.int64, device=device)
+    _lib.call("mcnerf_sample_perm", _p(out, torch.int64), int(n), int(batch), _p(seed, torch.int32), _stream())
+    return out
+
+
 def upload_f32(host_vals: Tensor, device) -> Tensor:
     """A small fp32 host tensor (<= 16 values) as a fresh device tensor, stream-ordered and without a host-device copy
     (the values travel as kernel arguments): the host never waits for the kernels already queued."""

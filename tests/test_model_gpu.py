@@ -165,7 +165,7 @@ def test_mc_model_joint_optimisation_step_matches_oracle(gpu_device, monkeypatch
     idx = torch.randperm(H * W, generator=g)[:B]
     draws = dict(jitter=torch.rand(B, 1, generator=g) * 7.0 / 32, eps_c=torch.randn(B, 32, generator=g),
                  eps_sel=torch.randn(B, 32, generator=g), eps_f=torch.randn(B, 64, generator=g))
-    monkeypatch.setattr(mm.torch, "randperm", lambda n, device=None: idx.to(device) if n == H * W else None)
+    model.sample_pixels = lambda npix: idx.to(dev)            # the reference's draw (randperm(H * W)[:batch], :329)
     orig = model.nerf.render_rays_train
     model.nerf.render_rays_train = lambda d, o, e, r, only_coarse=False: orig(
         d, o, e, r, only_coarse, **{k: v.to(dev) for k, v in draws.items()})
@@ -284,7 +284,7 @@ def test_mc_model_step_matches_reference_golden(gpu_device, monkeypatch):
     model = MC_Model(sp).to(dev)
     model.load_state_dict({k[2:]: t(v) for k, v in g.items() if k.startswith("p.")})
     idx = t(g["rand_idx"])
-    monkeypatch.setattr(mm.torch, "randperm", lambda n, device=None: idx.to(device))
+    model.sample_pixels = lambda npix: idx.to(dev)            # the golden step's pixel draw
     draws = {k: t(g[k]).to(dev) for k in ("jitter", "eps_c", "eps_sel", "eps_f")}
     orig = model.nerf.render_rays_train
     model.nerf.render_rays_train = lambda d, o, e, r, only_coarse=False: orig(d, o, e, r, only_coarse, **draws)

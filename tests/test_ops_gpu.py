@@ -498,3 +498,56 @@ def test_cap_random_device_side(gpu_device):
     assert int(c3.item()) == 1500
     got = torch.sort(idx3[:1500, 0].long() * 97 + idx3[:1500, 1].long()).values
     assert torch.equal(got, torch.arange(1500, device=dev))
+
+
+def test_sample_perm_is_a_random_subset_without_replacement(gpu_device):
+    """mcnerf_sample_perm = randperm(n)[:batch] of model/mc_nerf.py:329 in one kernel: distinct ids in range, every pixel
+    equally likely, random order, reproducible from the seed word; batch == n gives a full permutation."""
+    ops = _ops()
+    dev = gpu_device
+    n, batch = 800 * 800, 7000
+    hits = torch.zeros(n, device=dev)
+    first = torch.zeros(n, device=dev)
+    trials = 400
+    for t in range(trials):
+        seed = torch.tensor([7919 * t + 3], dtype=torch.int32, device=dev)
+        idx = ops.sample_perm(n, batch, dev, seed)
+        assert idx.dtype == torch.int64 and idx.shape == (batch,)
+        assert int(idx.min()) >= 0 and int(idx.max()) < n and torch.unique(idx).numel() == batch
+        hits[idx] += 1
+        first[idx[:100]] += 1
+    # pixel hit counts ~ Binomial(400, 7000 / 640000): mean 4.375, sd 2.08
+    assert abs(float(hits.mean()) - trials * batch / n) < 1e-9
+    assert float(hits.max()) <= 22
+    # no positional structure: quarters of the image and even/odd pixels are hit equally (sd of a quarter's share ~ 0.0006)
+    q = hits.view(4, -1).sum(1) / hits.sum()
+    assert float((q - 0.25).abs().max()) < 0.004
+    assert abs(float(hits[0::2].sum() / hits.sum()) - 0.5) < 0.004
+    # the ORDER is random too: the first 100 ids of a draw are spread like the whole draw
+    qf = first.view(4, -1).sum(1) / first.sum()
+    assert float((qf - 0.25).abs().max()) < 0.02
+    # seeded: same word -> same draw, another word -> another draw
+    s1 = torch.tensor([42], dtype=torch.int32, device=dev)
+    a, b = ops.sample_perm(n, batch, dev, s1), ops.sample_perm(n, batch, dev, s1)
+    c = ops.sample_perm(n, batch, dev, torch.tensor([43], dtype=torch.int32, device=dev))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    # a full permutation, also for a non-power-of-two n and n = 1
+    for m in (1, 2, 1000, 12345):
+        full = ops.sample_perm(m, m, dev, s1)
+        assert torch.equal(torch.sort(full).values, torch.arange(m, device=dev))
+    # torch.manual_seed drives the default seed word
+    torch.manual_seed(5); x = ops.sample_perm(n, 64, dev)
+    torch.manual_seed(5); y = ops.sample_perm(n, 64, dev)
+    assert torch.equal(x, y)
+
+
+def test_upload_f32_passes_host_values_bit_exactly(gpu_device):
+    """mcnerf_upload_f32: host floats travel as kernel arguments (no host-device copy) and arrive bit-exactly."""
+    ops = _ops()
+    for n in (1, 10, 16):
+        hv = torch.randn(n) * 10 ** torch.randint(-20, 20, (n,)).float()
+        out = ops.upload_f32(hv, gpu_device)
+        assert out.dtype == torch.float32 and out.is_cuda
+        assert torch.equal(out.cpu().view(torch.int32), hv.view(torch.int32))
+    emb_w = torch.tensor([1.0, 1.0, 0.75, 0.25, 0, 0, 0, 0, 0, 0])
+    assert torch.equal(ops.upload_f32(emb_w, gpu_device).cpu(), emb_w)
