@@ -45,8 +45,13 @@ B16 = {"fwd": 10 * 512 + 128 + 64 + 320 + 16 + 8,
 DTYPE_TEXT = {"f32": "f32", "f16x3": "f16x3 (split-f16 MFMA operands: 3 MFMAs per product, fp32 accumulate/storage)",
               "f16": "f16 (single-pass f16 MFMA operands, fp32 accumulate, 2-byte workspaces)",
               "bf16": "bf16 (single-pass bf16 MFMA operands, fp32 accumulate, 2-byte workspaces)"}
-WORKLOAD = ("Ball_Lego-shaped 110-view 800x800, coarse 4x128 @64 + fine 8x256 @128-grid, GLOBAL_OPTIM stage, "
-            "fwd+bwd+allreduce+RAdam")
+RIG_NAMES = {"ball": "Ball_Lego", "array": "Array_Ficus", "halfball": "HalfBall_Materials", "room": "Room_Statue"}
+
+
+def workload_text(args):
+    return (f"{RIG_NAMES[args.rig]}-shaped 110-view {args.img}x{args.img}, coarse 4x128 @{args.samples} + fine 8x256 "
+            f"@{args.samples * args.scale}-grid{' (<= 128 kept per ray, random cap)' if args.samples * args.scale > 128 else ''}, "
+            "GLOBAL_OPTIM stage, fwd+bwd+allreduce+RAdam")
 
 
 def launch_ranks(args, argv):
@@ -203,8 +208,9 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     from mc_nerf_amd.data import DeviceImageSet
 
     torch.manual_seed(42 + rank)                   # main.py:274-277: seed + rank
-    H = W = 800
-    sp = S.make_sys_param(dev, samples=64, scale=2, batch=args.rays, H=H, W=W, barf_mask=False, precision=precision)
+    H = W = args.img
+    sp = S.make_sys_param(dev, samples=args.samples, scale=args.scale, batch=args.rays, H=H, W=W, barf_mask=False,
+                          precision=precision, rig=args.rig)
     model = MC_Model(sp).to(dev)
     S.init_cameras_near_gt(model, noise=1e-3)
     loss_fn = MC_NeRF_Loss(sp)
@@ -290,7 +296,7 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
             per_call[f"mlp_{k}<256>"] = {"ms": ms, "mfma_TFLOPs": tf, "mfma_frac": tf / mfma_peak, "contract_bytes_per_launch": contract[k] * k_mean,
                                          "hbm_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS}
     rec["per_call"] = per_call
-    rec["step_algorithmic_tflop"] = 3 * (F_FINE * k_mean + F_COARSE * args.rays * 64) / 1e12
+    rec["step_algorithmic_tflop"] = 3 * (F_FINE * k_mean + F_COARSE * args.rays * args.samples) / 1e12
     rec["step_mfma_frac"] = rec["step_algorithmic_tflop"] / (dt / steps) / mfma_peak
     del model, opt, sync
     torch.cuda.empty_cache()
@@ -372,7 +378,7 @@ def run_rank(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
-            "config": {"workload": WORKLOAD, "precision": args.precision, "rays_per_step_per_gpu": args.rays,
+            "config": {"workload": workload_text(args), "precision": args.precision, "rays_per_step_per_gpu": args.rays,
                        "fine_samples_per_ray": head["fine_samples_per_ray"],
                        "parallelism": f"dp{world} (cameras sharded, 1 flat all-reduce/step)"},
             "roofline": roof,
@@ -440,6 +446,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=32768, help="rays per step per GPU (config `batch`)")
+    ap.add_argument("--samples", type=int, default=64, help="coarse samples per ray (config `samples`; reference default 128)")
+    ap.add_argument("--scale", type=int, default=2, help="fine grid = samples x scale (config `scale`; reference default 5), capped at 128 kept per ray")
+    ap.add_argument("--img", type=int, default=800, help="image side (BASELINE cfg 5: 1600)")
+    ap.add_argument("--rig", default="ball", choices=["ball", "array", "halfball", "room"], help="camera rig of the synthetic scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f16", choices=["f32", "f16x3", "f16", "bf16"],
                     help="MFMA mode of the MLP kernels: single-pass f16 / bf16 (throughput modes), split-f16 f16x3 or exact f32 "

@@ -10,13 +10,25 @@
 // Replaces autograd through model/net_block.py:22-33, 67-78 and model/mc_nerf.py:602, 635, 690-691.
 #include "mcnerf_16.h"
 
+#ifdef MCN16_STAMPS     // (diagnostic build: in-kernel cycle stamps of the pass phases, read back by scripts/stamps16_bwd.py)
+__device__ unsigned long long g_mcn16_bstamps[64 * 16];
+extern "C" int mcnerf_debug_stamps16_bwd(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mcn16_bstamps), sizeof(g_mcn16_bstamps));
+}
+#define MCN16_BSTAMP(i) do { if (W == 256 && blockIdx.x < 64 && pass == (long long)blockIdx.x + 20ll * gridDim.x && lane == 0 && wave == 0) \
+        g_mcn16_bstamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MCN16_BSTAMP(i) do { } while (0)
+#endif
+
 template <int W>
 struct Bwd16Smem {
     static constexpr int oW2 = MCN16_RING * MCN16_SLAB * 1024;     // sigma.2 weight row [W] fp32
     static constexpr int oBarf = oW2 + W * 4;                      // BARF weights [10] (+ pad)
     static constexpr int MW = W >= 64 ? W / 64 : 1;                 // mask dwords per lane and slot
     static constexpr int oMask = oBarf + 16 * 4;                    // per wave: 3 buffers of [MW][64] dwords (ReLU bits, fetched ahead by LDS-DMA)
-    static constexpr int total = oMask + MCN16_WAVES * 3 * MW * 256;
+    static constexpr int oIdx = oMask + MCN16_WAVES * 3 * MW * 256; // per wave: the NEXT pass's (ray, sample) pairs [32][2] (LDS-DMA, one pass ahead)
+    static constexpr int total = oIdx + MCN16_WAVES * 256;
 };
 
 // GEMM over one segment of NTILES output tiles x KSTEPS contraction steps (B fragments `in`), software-pipelined like
@@ -118,57 +130,103 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
     const float inv_sg = 1.0f / sg;
     __syncthreads();
 
+    // ---- the per-sample inputs of a pass are fetched ONE PASS AHEAD (software pipeline over the persistent loop): a pass
+    // starts with two dependent gathers (index pair -> ray / output rows) behind every store of the previous pass in the
+    // in-order vmcnt queue, 15.8 k of the 150 k cycles of a pass when taken at the top (in-kernel stamps).
+    // The index pairs of pass p + 1 go to LDS by DMA right after the prologue of pass p; the row gathers are issued
+    // when the GEMMs of pass p are done and land under its encoding backward.
+    struct In { int ray; float zg, jit; f32x4 o, go; float dx, dy, dz, ox, oy, oz; };
+    auto gather = [&](int ray, int j) -> In {
+        In r;
+        r.ray = ray;
+        r.zg = a.zgrid[j];
+        r.jit = a.jitter ? a.jitter[ray] : 0.f;
+        const size_t addr = (size_t)ray * a.S + j;
+        r.o = *reinterpret_cast<const f32x4*>(a.out + addr * 4);
+        r.go = *reinterpret_cast<const f32x4*>(a.d_out + addr * 4);
+        r.dx = a.rays_d[ray * 3]; r.dy = a.rays_d[ray * 3 + 1]; r.dz = a.rays_d[ray * 3 + 2];
+        r.ox = a.rays_o[ray * 3]; r.oy = a.rays_o[ray * 3 + 1]; r.oz = a.rays_o[ray * 3 + 2];
+        return r;
+    };
+    auto row_of = [&](long long pass_) -> long long {           // this lane's row of a pass, clamped into the list
+        const long long g_ = (pass_ * MCN16_WAVES + wave) * 32 + m;
+        return g_ < total ? g_ : total - 1;
+    };
+    In cur;
+    {
+        const long long gc0 = row_of(blockIdx.x);
+        int ray0, j0;
+        if (a.idx) { const int2 rj = a.idx[gc0]; ray0 = rj.x; j0 = rj.y; }
+        else { ray0 = (int)(gc0 / a.S); j0 = (int)(gc0 - (long long)ray0 * a.S); }
+        cur = gather(ray0, j0);
+    }
+
     Mcn16Ring ring;
     mcn16_ring_start(ring, smem, a.packed, a.stream_slabs, wave, lane);
     const float* w2_h = sw2 + 4 * h;
+    const unsigned idx_lds = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem) + SM::oIdx + wave * 256;
+
+    // ReLU bits of a slot are fetched by LDS-DMA into one of this wave's three buffers well ahead of their use (an
+    // ordinary load in the layer loop makes hipcc wait vmcnt(0) at its use: a full drain of the weight ring and of
+    // the workspace stores once per layer).  Slot x <= D-1 lives in buffer (D + 1 - x) % 3; D in 0, D + 1 in 1.
+    // Issue points are at least two segments ahead, so the counted ring waits in between cover their landing; the
+    // first three slots of a pass (D, D + 1, D - 1) are issued during the PREVIOUS pass's epilogue.
+    // Narrower nets (short layers: the drain is cheap, the extra DMA instructions are not: measured 0.75 vs 0.83 ms on
+    // the 4x128 net) use ordinary loads into a register set (`mpend`) one layer ahead of their use, the first three slots
+    // one pass ahead (mk0_*).
+    constexpr bool MASK_DMA = W >= 256;
+    const unsigned mlds = ring.lds_base + SM::oMask + wave * (3 * MW * 256);
+    auto mask_issue = [&](const unsigned* mask_lane, int slot, int buf) {
+        if (MASK_DMA) {
+#pragma unroll
+            for (int i = 0; i < MW; ++i) mcn16_dma4(mask_lane + (size_t)slot * a.mask_slot_words + i, mlds + (buf * MW + i) * 256);
+        }
+    };
+    auto mask_read = [&](const unsigned* mask_lane, unsigned (&mk)[MW], int buf, int slot) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            if (MASK_DMA) mk[i] = *reinterpret_cast<const unsigned*>(smem + SM::oMask + wave * (3 * MW * 256) + (buf * MW + i) * 256 + lane * 4);
+            else mk[i] = mask_lane[(size_t)slot * a.mask_slot_words + i];
+        }
+    };
+    auto buf_of = [&](int slot) { return (D + 1 - slot) % 3; };
+#ifdef ABL16_MASKL2
+    auto mask_lane_of = [&](long long pass_) { return a.mask_ws + ((size_t)((pass_ * MCN16_WAVES + wave) & 63) * 64 + lane) * MW; };
+#else
+    auto mask_lane_of = [&](long long pass_) { return a.mask_ws + ((size_t)(pass_ * MCN16_WAVES + wave) * 64 + lane) * MW; };
+#endif
+    unsigned mk0_s[MW], mk0_c[MW], mk0_t[MW];                  // (narrow nets) the first three slots of the coming pass
+    {
+        const unsigned* ml0 = mask_lane_of(blockIdx.x);
+        mask_issue(ml0, D, 0); mask_issue(ml0, D + 1, 1); mask_issue(ml0, D - 1, 2);
+        if (!MASK_DMA) { mask_read(ml0, mk0_s, 0, D); mask_read(ml0, mk0_c, 1, D + 1); mask_read(ml0, mk0_t, 2, D - 1); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
     for (long long pass = blockIdx.x; pass * MCN16_ROWS < total; pass += gridDim.x) {
         const long long tile = pass * MCN16_WAVES + wave;
         const long long g = tile * 32 + m;
         const bool valid = g < total;
-        const long long gc = valid ? g : total - 1;
+#ifdef ABL16_MASKL2      // (timing-only ablation: every pass reads the same few mask tiles = the reads hit in L2)
+        const unsigned* mask_lane = a.mask_ws + ((size_t)(tile & 63) * 64 + lane) * MW;
+#else
         const unsigned* mask_lane = a.mask_ws + ((size_t)tile * 64 + lane) * MW;
+#endif
         char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)tile * KS * 1024 + lane * 16;
-        // ReLU bits of a slot are fetched by LDS-DMA into one of this wave's three buffers well ahead of their use (an
-        // ordinary load in the layer loop makes hipcc wait vmcnt(0) at its use: a full drain of the weight ring and of
-        // the workspace stores once per layer).  Slot x <= D-1 lives in buffer (D + 1 - x) % 3; D in 0, D + 1 in 1.
-        // Issue points are at least two segments ahead, so the counted ring waits in between cover their landing
-        // (W >= 128); the narrow test nets drain explicitly.
-        // Narrower nets (short layers: the drain is cheap, the extra DMA instructions are not: measured 0.75 vs 0.83 ms on
-        // the 4x128 net) use ordinary loads into a register set (`mpend`) one layer ahead of their use.
-        constexpr bool MASK_DMA = W >= 256;
-        const unsigned mlds = ring.lds_base + SM::oMask + wave * (3 * MW * 256);
-        auto mask_issue = [&](int slot, int buf) {
-            if (MASK_DMA) {
-#pragma unroll
-                for (int i = 0; i < MW; ++i) mcn16_dma4(mask_lane + (size_t)slot * a.mask_slot_words + i, mlds + (buf * MW + i) * 256);
-            }
-        };
-        auto mask_read = [&](unsigned (&mk)[MW], int buf, int slot) {
-#pragma unroll
-            for (int i = 0; i < MW; ++i) {
-                if (MASK_DMA) mk[i] = *reinterpret_cast<const unsigned*>(smem + SM::oMask + wave * (3 * MW * 256) + (buf * MW + i) * 256 + lane * 4);
-                else mk[i] = mask_lane[(size_t)slot * a.mask_slot_words + i];
-            }
-        };
-        auto buf_of = [&](int slot) { return (D + 1 - slot) % 3; };
-        mask_issue(D, 0); mask_issue(D + 1, 1); mask_issue(D - 1, 2);
+        MCN16_BSTAMP(0);
         // ---- per-sample prologue (lane-local): sigmoid and SH backward
-        int ray, j;
-        if (a.idx) { const int2 rj = a.idx[gc]; ray = rj.x; j = rj.y; }
-        else { ray = (int)(gc / a.S); j = (int)(gc - (long long)ray * a.S); }
+        const int ray = cur.ray;
         unsigned mk_s[MW], mk_c[MW], mk_t[MW];
-        float zv = a.zgrid[j];
-        if (a.jitter) zv = __fadd_rn(zv, a.jitter[ray]);
-        const size_t addr = (size_t)ray * a.S + j;
-        const f32x4 o = *reinterpret_cast<const f32x4*>(a.out + addr * 4);
-        f32x4 go = *reinterpret_cast<const f32x4*>(a.d_out + addr * 4);
+        float zv = cur.zg;
+        if (a.jitter) zv = __fadd_rn(zv, cur.jit);
+        const f32x4 o = cur.o;
+        f32x4 go = cur.go;
         if (!valid) go = f32x4{0.f, 0.f, 0.f, 0.f};          // rows past the count contribute exactly zero everywhere
-        const float x = a.rays_d[ray * 3], y = a.rays_d[ray * 3 + 1], z = a.rays_d[ray * 3 + 2];
+        const float x = cur.dx, y = cur.dy, z = cur.dz;
         float p[3];
-        p[0] = __fadd_rn(a.rays_o[ray * 3 + 0], __fmul_rn(x, zv));
-        p[1] = __fadd_rn(a.rays_o[ray * 3 + 1], __fmul_rn(y, zv));
-        p[2] = __fadd_rn(a.rays_o[ray * 3 + 2], __fmul_rn(z, zv));
+        p[0] = __fadd_rn(cur.ox, __fmul_rn(x, zv));
+        p[1] = __fadd_rn(cur.oy, __fmul_rn(y, zv));
+        p[2] = __fadd_rn(cur.oz, __fmul_rn(z, zv));
         float bas[9];
         mcn_sh_basis(x, y, z, bas);
         float dpre[3];
@@ -198,11 +256,18 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
             mcn16_ws_store(dshf[1], reinterpret_cast<u32x4_t*>(e + 1024));
         }
 
-        if (!MASK_DMA) { mask_read(mk_s, 0, D); mask_read(mk_c, 1, D + 1); mask_read(mk_t, 2, D - 1); }     // (with the prologue's other loads)
-        if (MASK_DMA) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the prologue's loads and the first three mask buffers have landed
-            mask_read(mk_s, 0, D);
+        // (the first three mask slots and the per-sample inputs were fetched during the previous pass and waited for at its end)
+        if (MASK_DMA) mask_read(mask_lane, mk_s, 0, D);
+        else {
+#pragma unroll
+            for (int i = 0; i < MW; ++i) { mk_s[i] = mk0_s[i]; mk_c[i] = mk0_c[i]; mk_t[i] = mk0_t[i]; }
         }
+        const long long pass_n = pass + gridDim.x;
+        if (a.idx) {       // lane L fetches dword L of the next pass's 32 (ray, sample) pairs
+            const long long gn = (pass_n * MCN16_WAVES + wave) * 32 + (lane >> 1);
+            mcn16_dma4(reinterpret_cast<const int*>(a.idx) + 2 * (gn < total ? gn : total - 1) + (lane & 1), idx_lds);
+        }
+        MCN16_BSTAMP(1);
         u32x4_t xa[KS], xb[KS];
         f32x16 denc[2];
         u32x4_t dencp[4];            // the skip layer's share of the encoded-input gradient, parked in 16 bit until layer 0
@@ -222,33 +287,43 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
             mcn16_ws_store(xa[s], reinterpret_cast<u32x4_t*>(dy_lane + (size_t)D * a.slot_bytes + s * 1024));
         }
         // ---- sigma.0^T (partial, 16 bit) ; sh.2^T -> dY of sh.0 ; sh.0^T + partial -> dY_{D-1}
-        if (D >= 2) mask_issue(D - 2, buf_of(D - 2));          // buffer 0 is free (the sigma path is done)
+        MCN16_BSTAMP(2);
+        if (D >= 2) mask_issue(mask_lane, D - 2, buf_of(D - 2));          // buffer 0 is free (the sigma path is done)
         unsigned mpend[MW];
-        if (!MASK_DMA && D >= 2) mask_read(mpend, 0, D - 2);
+        if (!MASK_DMA && D >= 2) mask_read(mask_lane, mpend, 0, D - 2);
         mcn16_bwd_seg<W, BF, KS, NT, 0>(ring, smem, lane, xa, xb, mk_s, denc, nullptr);
-        if (MASK_DMA) mask_read(mk_c, 1, D + 1);
+        MCN16_BSTAMP(3);
+        if (MASK_DMA) mask_read(mask_lane, mk_c, 1, D + 1);
         {
             u32x4_t dsh_in[KS];
             dsh_in[0] = dshf[0]; dsh_in[1] = dshf[1];
             mcn16_bwd_seg<W, BF, 2, NT, 1>(ring, smem, lane, dsh_in, xa, mk_c, denc, dy_lane + (size_t)(D + 1) * a.slot_bytes);
         }
-        if (D >= 3) mask_issue(D - 3, buf_of(D - 3));          // buffer 1 is free (sh.2^T is done)
-        if (MASK_DMA) mask_read(mk_t, 2, D - 1);
+        MCN16_BSTAMP(4);
+        if (D >= 3) mask_issue(mask_lane, D - 3, buf_of(D - 3));          // buffer 1 is free (sh.2^T is done)
+        if (MASK_DMA) mask_read(mask_lane, mk_t, 2, D - 1);
         mcn16_bwd_seg<W, BF, KS, NT, 2>(ring, smem, lane, xa, xb, mk_t, denc, dy_lane + (size_t)(D - 1) * a.slot_bytes);
+        MCN16_BSTAMP(5);
         // ---- trunk, last layer to first: xb = dY_l
         for (int l = D - 1; l >= 1; --l) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) xa[s] = xb[s];
             if (MASK_DMA) {
-                if (l >= 3) mask_issue(l - 3, buf_of(l - 3));  // the buffer of slot l (previous segment) is free
-                mask_read(mk_t, buf_of(l - 1), l - 1);
+                if (l >= 3) mask_issue(mask_lane, l - 3, buf_of(l - 3));  // the buffer of slot l (previous segment) is free
+                mask_read(mask_lane, mk_t, buf_of(l - 1), l - 1);
             } else {
 #pragma unroll
                 for (int i = 0; i < MW; ++i) mk_t[i] = mpend[i];
-                if (l >= 2) mask_read(mpend, 0, l - 2);
+                if (l >= 2) mask_read(mask_lane, mpend, 0, l - 2);
+            }
+            if (l == 1 && pass_n * MCN16_ROWS < total) {      // (workgroup-uniform) every buffer is free from here on: the next pass's first three slots
+                const unsigned* mln = mask_lane_of(pass_n);
+                mask_issue(mln, D, 0); mask_issue(mln, D + 1, 1); mask_issue(mln, D - 1, 2);
+                if (!MASK_DMA) { mask_read(mln, mk0_s, 0, D); mask_read(mln, mk0_c, 1, D + 1); mask_read(mln, mk0_t, 2, D - 1); }
             }
             if (l == skip) mcn16_bwd_seg<W, BF, KS, 2, 0, 4>(ring, smem, lane, xa, dencp, mk_t, denc, nullptr);
             mcn16_bwd_seg<W, BF, KS, NT, 1>(ring, smem, lane, xa, xb, mk_t, denc, dy_lane + (size_t)(l - 1) * a.slot_bytes);
+            MCN16_BSTAMP(5 + D - l);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -257,10 +332,42 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
                 denc[t][2 * d] = T::lo(dencp[2 * t][d]); denc[t][2 * d + 1] = T::hi(dencp[2 * t][d]);
                 denc[t][8 + 2 * d] = T::lo(dencp[2 * t + 1][d]); denc[t][8 + 2 * d + 1] = T::hi(dencp[2 * t + 1][d]);
             }
+        // ---- the next pass's rows: index pair from LDS (DMA'd during this pass's prologue), gathers land under the last GEMM and the epilogue (memory latency under this load is several us)
+        In nxt;
+        {
+            int rn, jn;
+            if (a.idx) {
+                const int2 rj = *reinterpret_cast<const int2*>(smem + SM::oIdx + wave * 256 + m * 8);
+                rn = rj.x; jn = rj.y;
+            } else {
+                const long long gn = row_of(pass_n);
+                rn = (int)(gn / a.S); jn = (int)(gn - (long long)rn * a.S);
+            }
+            nxt = gather(rn, jn);
+        }
+        // (the saved sh.2 outputs for the view-direction term are fetched under the last GEMM)
+        const bool want_rays = a.d_rays_o || a.d_rays_d;
+        u32x4_t shs0 = {0u, 0u, 0u, 0u}, shs1 = {0u, 0u, 0u, 0u};
+        if (want_rays) {
+            shs0 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 2 * 1024 + lane * 16);
+            shs1 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 2 * 1024 + 1024 + lane * 16);
+        }
         mcn16_bwd_seg<W, BF, KS, 2, 3>(ring, smem, lane, xb, xa, mk_t, denc, nullptr);       // layer 0: encoded columns
+        MCN16_BSTAMP(13);
+        // everything fetched for the next pass is waited for HERE, in front of the ray atomics (long landed: issued a whole
+        // encoding backward earlier), so that the top of the next pass waits for nothing -- least of all for those atomics
+        auto settle = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(nxt.ray), "+v"(nxt.zg), "+v"(nxt.jit), "+v"(nxt.o), "+v"(nxt.go));
+            asm volatile("" : "+v"(nxt.dx), "+v"(nxt.dy), "+v"(nxt.dz), "+v"(nxt.ox), "+v"(nxt.oy), "+v"(nxt.oz));
+            if (!MASK_DMA) {
+#pragma unroll
+                for (int i = 0; i < MW; ++i) asm volatile("" : "+v"(mk0_s[i]), "+v"(mk0_c[i]), "+v"(mk0_t[i]));
+            }
+        };
 
         // ---- encoding backward -> d position; SH view-direction term; per-ray reduction
-        if (a.d_rays_o || a.d_rays_d) {
+        if (want_rays) {
             // this lane holds d enc of channels 32 te + 8 q + 4 h + e (register 4 q + e of denc[te]); channel 3 + 20 a + f is
             // w_f sin(2^f x_a), + 10: w_f cos(2^f x_a)  ->  d x_a += 2^f w_f (cos dsin - sin dcos)
             auto dch = [&](int ch) -> float {              // d enc of channel ch if this lane half holds it, else 0
@@ -287,8 +394,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
             // SH term: d pre_c / d dir = sum_i sh[9c + i] d basis_i / d dir with the forward's saved sh.2 outputs (model/net_utils.py:154-169)
             float ddir[3] = {0.f, 0.f, 0.f};
             {
-                const u32x4_t s0 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 2 * 1024 + lane * 16);
-                const u32x4_t s1 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 2 * 1024 + 1024 + lane * 16);
+                const u32x4_t s0 = shs0, s1 = shs1;
                 const float C1 = 0.4886025119029199f, C20 = 1.0925484305920792f, C22 = 0.31539156525252005f, C24 = 0.5462742152960396f;
                 // derivative of basis i wrt (x, y, z)
                 const float gx[9] = {0.f, 0.f, 0.f, -C1, C20 * y, 0.f, -2.f * C22 * x, -C20 * z, 2.f * C24 * x};
@@ -315,6 +421,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
                 red[c] = dp * inv_sg;                              // d origin
                 red[3 + c] = (dp * zv + dd) * inv_sg;              // d direction: through x = o + d z, plus the SH term
             }
+            settle();
             // segmented inclusive scan over the 32 samples (rows of one ray are contiguous): the last row of each run adds
             // the run's sum with 6 atomics instead of 6 per sample
             const int rkey = valid ? ray : -1;
@@ -337,6 +444,9 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
                 }
             }
         }
+        if (!want_rays) settle();
+        MCN16_BSTAMP(14);
+        cur = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -157,6 +157,17 @@ __device__ __forceinline__ void mcn16_layer(Mcn16Ring& ring, char* smem, int lan
     }
 }
 
+#ifdef MCN16_STAMPS     // (diagnostic build: in-kernel cycle stamps of the pass phases, read back by scripts/stamps16.py)
+__device__ unsigned long long g_mcn16_fstamps[2 * 64 * 16];
+extern "C" int mcnerf_debug_stamps16_fwd(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mcn16_fstamps), sizeof(g_mcn16_fstamps));
+}
+#define MCN16_FSTAMP(i) do { if (W == 256 && blockIdx.x < 64 && pass == (long long)blockIdx.x + 20ll * gridDim.x && lane == 0 && wave == 0) \
+        g_mcn16_fstamps[((SAVE ? 64 : 0) + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MCN16_FSTAMP(i) do { } while (0)
+#endif
+
 template <int W, bool SAVE, bool BF>
 __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16FwdArgs a) {
     using T = Mcn16T<BF>;
@@ -198,6 +209,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
         const long long g = tile * 32 + m;
         const bool valid = g < total;
         const long long gc = valid ? g : total - 1;
+        MCN16_FSTAMP(0);
         // ---- per-sample setup (lane-local; both lane halves of a sample compute the same values)
         int ray, j;
         if (a.idx) { const int2 rj = a.idx[gc]; ray = rj.x; j = rj.y; }
@@ -227,8 +239,10 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
 
         u32x4_t xa[KS], xb[KS];
         float dot = 0.f;
+        MCN16_FSTAMP(1);
         // ---- layer 0 (encoded input only), then the trunk; the skip layer takes [encoding, hidden]
         mcn16_layer<W, BF, SAVE, MCN16_ENCKS, 0, 0>(ring, smem, lane, encf, xa, xb, bias_h, nullptr, dot, act_lane, mask_lane);
+        MCN16_FSTAMP(2);
         for (int l = 1; l < D; ++l) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) xa[s] = xb[s];
@@ -236,15 +250,18 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
             unsigned* ml = SAVE ? mask_lane + (size_t)l * a.mask_slot_words : nullptr;
             if (l == skip) mcn16_layer<W, BF, SAVE, MCN16_ENCKS, KS, 0>(ring, smem, lane, encf, xa, xb, bias_h + l * W, nullptr, dot, sl, ml);
             else mcn16_layer<W, BF, SAVE, 0, KS, 0>(ring, smem, lane, encf, xa, xb, bias_h + l * W, nullptr, dot, sl, ml);
+            MCN16_FSTAMP(2 + l);
         }
         // ---- sigma head: hidden layer on the matrix pipe, the 1-wide output layer lane-local
         mcn16_layer<W, BF, SAVE, 0, KS, 1>(ring, smem, lane, encf, xb, xa, bias_h + D * W, w2_h, dot,
                                            SAVE ? act_lane + (size_t)D * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)D * a.mask_slot_words : nullptr);
+        MCN16_FSTAMP(10);
         // ---- SH head: hidden layer (reads the same trunk output), then the 27 (32) coefficient rows
 #ifndef ABL16_NOSHHIDDEN   // (timing-only ablation: one 128-MFMA layer body less in the instruction stream)
         mcn16_layer<W, BF, SAVE, 0, KS, 0>(ring, smem, lane, encf, xb, xa, bias_h + (D + 1) * W, nullptr, dot,
                                            SAVE ? act_lane + (size_t)(D + 1) * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)(D + 1) * a.mask_slot_words : nullptr);
 #endif
+        MCN16_FSTAMP(11);
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -261,6 +278,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
                 acc = T::mfma(af, xa[s], acc);
             }
         }
+        MCN16_FSTAMP(12);
         if (SAVE) {          // the SH coefficients (bias included) for the backward's view-direction term: 2 fragments of 16 bit
             char* e = reinterpret_cast<char*>(a.sh_ws) + (size_t)tile * 2 * 1024 + lane * 16;
             u32x4_t s0, s1;
@@ -297,6 +315,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
             o[1 + c] = 1.0f / (1.0f + expf(-pc));
         }
         if (valid && h == 0) *reinterpret_cast<f32x4*>(a.out + (size_t)addr * 4) = o;
+        MCN16_FSTAMP(13);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ring pieces still in flight must land before the LDS is released
 }
