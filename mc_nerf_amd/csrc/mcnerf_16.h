@@ -234,6 +234,9 @@ struct Mcn16Ring {
     unsigned issue_slot;      // ring slot (0..RING-1) of the next issue
     unsigned sync_slot;       // ring slot of the next slab to synchronise
     unsigned next_off;        // LDS byte offset of the slab synchronised last (the one after the slab being consumed)
+#ifdef ABL16_NORING
+    bool first_fill;
+#endif
 };
 typedef __attribute__((address_space(3))) void* mcn16_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* mcn16_gbl_ptr_t;
@@ -262,15 +265,26 @@ __device__ __forceinline__ void mcn16_dma4(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void mcn16_ring_issue(Mcn16Ring& r, char* ring_lds) {
     const char* s = r.src + (size_t)r.src_slab * (MCN16_SLAB * 1024);
     const unsigned d = r.lds_base + r.issue_slot * (MCN16_SLAB * 1024) + r.lds_piece;
+#ifndef ABL16_NORING            // (timing experiment only: the ring is filled once and never refilled)
 #pragma unroll
     for (int i = 0; i < MCN16_PPW; ++i) mcn16_dma16(s + i * 1024, d + i * 1024);
+#else
+    if (r.first_fill) {
+#pragma unroll
+        for (int i = 0; i < MCN16_PPW; ++i) mcn16_dma16(s + i * 1024, d + i * 1024);
+    }
+#endif
     r.src_slab = (r.src_slab + 1 == r.n_slabs) ? 0 : r.src_slab + 1;
     r.issue_slot = (r.issue_slot + 1) & (MCN16_RING - 1);
 }
 // Synchronise the next slab: wait for this wave's pieces of it, rendezvous (every wave's pieces have landed), refill
 // the ring AHEAD slabs further on.  r.next_off = the slab's LDS byte offset.
 __device__ __forceinline__ void mcn16_ring_sync(Mcn16Ring& r, char* ring_lds) {
-#ifdef MCN16_EXP_VMCNT      // (timing experiment only: a larger count is NOT safe in general)
+#if defined(ABL16_NOBARRIER)   // (timing experiments only: NOT safe)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MCN16_PPW * (MCN16_AHEAD - 1)) : "memory");
+#elif defined(ABL16_NOSYNC)
+    asm volatile("" ::: "memory");
+#elif defined(MCN16_EXP_VMCNT)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MCN16_EXP_VMCNT) : "memory");
 #else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MCN16_PPW * (MCN16_AHEAD - 1)) : "memory");
@@ -284,9 +298,17 @@ __device__ __forceinline__ void mcn16_ring_start(Mcn16Ring& r, char* ring_lds, c
     r.lds_piece = (MCN16_PPW * wave) * 1024;
     r.lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)ring_lds);
     r.src_slab = 0; r.n_slabs = n_slabs; r.issue_slot = 0; r.sync_slot = 0; r.next_off = 0;
+#ifdef ABL16_NORING
+    r.first_fill = true;
+#endif
 #pragma unroll
     for (int i = 0; i < MCN16_AHEAD; ++i) mcn16_ring_issue(r, ring_lds);
     mcn16_ring_sync(r, ring_lds);
+#ifdef ABL16_NORING
+    mcn16_ring_issue(r, ring_lds); mcn16_ring_issue(r, ring_lds);
+    r.issue_slot = (r.issue_slot + MCN16_RING - 2) & (MCN16_RING - 1);
+    r.first_fill = false;
+#endif
 }
 
 // One output tile's MFMA chain position inside a layer of F fragments: fragment f is read from the slab being consumed
