@@ -284,6 +284,7 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     if world > 1:
         rec["allreduce_ms"] = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
         rec["params_identical_across_ranks"] = in_sync
+        rec["asymmetric_grad_steps"] = sync.asymmetric_steps()      # ranks disagreeing on which tensors have gradients: must be 0
     # roofline of the fine-net kernels with ALGORITHMIC work per launch over the HIP-event launch time
     mfma_peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
     contract = B16 if precision in ("f16", "bf16") else B32
@@ -384,7 +385,7 @@ def run_rank(args):
             "roofline": roof,
             "by_precision": {p: {k: v for k, v in r.items() if k != "precision"} for p, r in others.items()},
         }
-        for k in ("allreduce_ms", "params_identical_across_ranks", "finite"):
+        for k in ("allreduce_ms", "params_identical_across_ranks", "asymmetric_grad_steps", "finite"):
             if k in head:
                 out[k] = head[k]
         if world == 1 and not args.no_cpu_baseline:

@@ -61,8 +61,13 @@ class FlatGradSync:
     size = DDP's averaging) and the parameters' `.grad` are pointed at / refreshed from it.
     """
 
-    def __init__(self, model, world: int):
-        self.model, self.world = model, world
+    def __init__(self, model, world: int, check_flags: bool = False):
+        """`check_flags=True` reads the reduced "some rank has a gradient" flags back every step (one device -> host
+        synchronisation per step) and gives a parameter the reduced gradient whenever ANY rank produced one.  The default
+        keeps the step free of host synchronisation: it assumes what main.py guarantees -- every rank runs the same stage,
+        so the set of parameters with a gradient is the same on every rank -- and only COUNTS violations on the device
+        (`asymmetric_steps()`)."""
+        self.model, self.world, self.check_flags = model, world, check_flags
         nerf = model.nerf
         self.nets = [nerf.nerf_coarse, nerf.nerf_fine]
         for n in self.nets:
@@ -76,6 +81,8 @@ class FlatGradSync:
         self.total = self.n_grad + self.n_flags
         dev = self.nets[0].flat_params().device
         self.arena = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self._flag_cache = {}                      # tuple of local flags -> device tensor (no per-step host -> device copy)
+        self._asym = torch.zeros((), dtype=torch.int32, device=dev)
 
     def broadcast_parameters(self):
         """Rank 0's parameters to everyone (what the DDP constructor does, main.py:61)."""
@@ -103,6 +110,10 @@ class FlatGradSync:
         """Call once after the step's single backward()."""
         nerf = self.model.nerf
         used = getattr(nerf, "grad_arena_used", False)
+        if self.world <= 1:                        # nothing to reduce: the gradients stay where backward() put them
+            nerf.grad_arena = None
+            nerf.grad_arena_used = False
+            return
         pairs, have = [], []
         o = 0
         for n, sz in zip(self.nets, self.net_sizes):
@@ -120,16 +131,28 @@ class FlatGradSync:
             pairs.append((p, v))
             have.append(1.0 if p.grad is not None else 0.0)
             o += sz
-        if self.world > 1:
-            self.arena[self.n_grad:].copy_(torch.tensor(have, dtype=torch.float32), non_blocking=True)
-            dist.all_reduce(self.arena, op=dist.ReduceOp.SUM)     # the step's ONE collective
-            self.arena[:self.n_grad].div_(self.world)
-            have = self.arena[self.n_grad:].tolist()              # (tiny D2H after the collective; the optimiser step follows anyway)
-        # A reduced slice becomes its parameter's gradient whenever ANY rank produced one (DDP semantics: a parameter unused
-        # on this rank but used elsewhere still receives the averaged gradient, otherwise the replicas diverge); parameters
-        # without a gradient on every rank (a stage that does not touch them) keep `.grad = None`, so the optimiser
-        # skips them exactly as in the reference.
+        key = tuple(have)
+        local = self._flag_cache.get(key)
+        if local is None:                          # (first step of a stage only)
+            local = self._flag_cache[key] = torch.tensor(have, dtype=torch.float32, device=self.arena.device)
+        self.arena[self.n_grad:].copy_(local)
+        dist.all_reduce(self.arena, op=dist.ReduceOp.SUM)     # the step's ONE collective
+        self.arena[:self.n_grad].div_(self.world)
+        if self.check_flags:
+            have = self.arena[self.n_grad:].tolist()          # (device -> host synchronisation)
+        else:                                      # same flags on every rank <=> reduced == world * local; count the steps where not
+            self._asym += (self.arena[self.n_grad:] != local * self.world).any().to(torch.int32)
+        # A reduced slice becomes its parameter's gradient whenever a rank produced one (DDP semantics: a parameter unused
+        # on this rank but used elsewhere still receives the averaged gradient, otherwise the replicas diverge -- with
+        # check_flags; without it the ranks are assumed to run the same stage and a violation is counted); parameters
+        # without a gradient (a stage that does not touch them) keep `.grad = None`, so the optimiser skips them exactly
+        # as in the reference.
         for (p, v), h in zip(pairs, have):
             p.grad = v if h > 0 else None
         nerf.grad_arena = None
         nerf.grad_arena_used = False
+
+    def asymmetric_steps(self) -> int:
+        """Steps (since construction) in which the ranks disagreed on which parameters have a gradient while `check_flags` was
+        off (one device -> host read; call it at an epoch boundary).  Must be 0."""
+        return int(self._asym.item())

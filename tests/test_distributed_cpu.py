@@ -61,7 +61,7 @@ def _worker(rank, world, port, q):
         _worker_body(rank, world, port, q)
     except Exception as e:                       # surface the failure instead of a queue timeout
         import traceback
-        q.put((rank, "error", traceback.format_exc(), None))
+        q.put((rank, "error", traceback.format_exc(), None, None))
         raise
 
 
@@ -95,7 +95,21 @@ def _worker_body(rank, world, port, q):
     sync.sync()
     out = {n: (p.grad.clone() if p.grad is not None else None) for n, p in model.named_parameters()}
     as_np = lambda d: {k: (None if v is None else v.numpy().copy()) for k, v in d.items()}   # pickle by value
-    q.put((rank, same_after_bcast, as_np(mine), as_np(out)))
+    sym_count = sync.asymmetric_steps()                        # both ranks had gradients for the same tensors so far
+    # an ASYMMETRIC step: only rank 1 has a gradient for one NeRF tensor
+    name3, p3 = list(model.nerf.named_parameters())[2]
+    strict = D.FlatGradSync(model, world, check_flags=True)    # reads the flags back: DDP's any-rank semantics
+    strict.prepare()
+    if rank == 1:
+        p3.grad = torch.full_like(p3, 4.0)
+    strict.sync()
+    any_rank = None if p3.grad is None else float(p3.grad.mean())
+    sync.prepare()                                             # default mode: no host sync, the violation is counted
+    if rank == 1:
+        p3.grad = torch.full_like(p3, 4.0)
+    sync.sync()
+    extra = dict(sym_count=sym_count, any_rank=any_rank, asym_count=sync.asymmetric_steps())
+    q.put((rank, same_after_bcast, as_np(mine), as_np(out), extra))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -115,8 +129,13 @@ def test_two_rank_flat_allreduce_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, b0, mine0, out0), (_, b1, mine1, out1) = res
+    (_, b0, mine0, out0, x0), (_, b1, mine1, out1, x1) = res
     assert b0 and b1
+    # flag handling: symmetric steps are not counted; with check_flags a gradient present on ONE rank reaches both (4 / 2 ranks);
+    # without it the step is counted on both ranks
+    assert x0["sym_count"] == 0 and x1["sym_count"] == 0
+    assert x0["any_rank"] == 2.0 and x1["any_rank"] == 2.0
+    assert x0["asym_count"] == 1 and x1["asym_count"] == 1
     n_checked = 0
     for name in out0:
         if mine0[name] is None and mine1[name] is None:
