@@ -62,11 +62,12 @@ class FlatGradSync:
     """
 
     def __init__(self, model, world: int, check_flags: bool = False):
-        """`check_flags=True` reads the reduced "some rank has a gradient" flags back every step (one device -> host
-        synchronisation per step) and gives a parameter the reduced gradient whenever ANY rank produced one.  The default
-        keeps the step free of host synchronisation: it assumes what main.py guarantees -- every rank runs the same stage,
-        so the set of parameters with a gradient is the same on every rank -- and only COUNTS violations on the device
-        (`asymmetric_steps()`)."""
+        """A parameter receives the reduced gradient whenever ANY rank produced one (DDP semantics).  Deciding that needs the
+        reduced "some rank has a gradient" flags on the host.  `check_flags=True` reads them back every step (one device ->
+        host synchronisation per step).  The default reads them back only the FIRST time a local flag pattern occurs (a
+        pattern changes at stage boundaries: a handful of reads per training): if the ranks agree the pattern is trusted
+        from then on and the step runs without host synchronisation, disagreement switches this object to `check_flags`
+        for good; later disagreement under a trusted pattern is still counted on the device (`asymmetric_steps()`)."""
         self.model, self.world, self.check_flags = model, world, check_flags
         nerf = model.nerf
         self.nets = [nerf.nerf_coarse, nerf.nerf_fine]
@@ -82,6 +83,7 @@ class FlatGradSync:
         dev = self.nets[0].flat_params().device
         self.arena = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self._flag_cache = {}                      # tuple of local flags -> device tensor (no per-step host -> device copy)
+        self._trusted = set()                      # local flag patterns verified to be the same on every rank
         self._asym = torch.zeros((), dtype=torch.int32, device=dev)
 
     def broadcast_parameters(self):
@@ -138,9 +140,16 @@ class FlatGradSync:
         self.arena[self.n_grad:].copy_(local)
         dist.all_reduce(self.arena, op=dist.ReduceOp.SUM)     # the step's ONE collective
         self.arena[:self.n_grad].div_(self.world)
-        if self.check_flags:
-            have = self.arena[self.n_grad:].tolist()          # (device -> host synchronisation)
-        else:                                      # same flags on every rank <=> reduced == world * local; count the steps where not
+        if self.check_flags or key not in self._trusted:
+            reduced = self.arena[self.n_grad:].tolist()       # (device -> host synchronisation)
+            if all((r > 0) == (h > 0) and (r == 0 or r == self.world) for r, h in zip(reduced, have)):
+                self._trusted.add(key)
+            elif not self.check_flags:
+                import logging
+                logging.warning("FlatGradSync: the ranks disagree on which parameters have gradients; reading the flags back every step from now on")
+                self.check_flags = True
+            have = reduced
+        else:                                      # trusted pattern: same flags on every rank <=> reduced == world * local; count the steps where not
             self._asym += (self.arena[self.n_grad:] != local * self.world).any().to(torch.int32)
         # A reduced slice becomes its parameter's gradient whenever a rank produced one (DDP semantics: a parameter unused
         # on this rank but used elsewhere still receives the averaged gradient, otherwise the replicas diverge -- with
@@ -153,6 +162,7 @@ class FlatGradSync:
         nerf.grad_arena_used = False
 
     def asymmetric_steps(self) -> int:
-        """Steps (since construction) in which the ranks disagreed on which parameters have a gradient while `check_flags` was
-        off (one device -> host read; call it at an epoch boundary).  Must be 0."""
+        """Steps (since construction) in which the ranks disagreed on which parameters have a gradient under a pattern that
+        had been verified earlier, i.e. steps whose flags were not read back (one device -> host read; call it at an epoch
+        boundary).  Must be 0."""
         return int(self._asym.item())

@@ -104,11 +104,15 @@ def _worker_body(rank, world, port, q):
         p3.grad = torch.full_like(p3, 4.0)
     strict.sync()
     any_rank = None if p3.grad is None else float(p3.grad.mean())
-    sync.prepare()                                             # default mode: no host sync, the violation is counted
+    # default mode: a local pattern seen for the first time is verified against the reduced flags -> the disagreement is found,
+    # the any-rank rule applies and the object reads the flags back from then on
+    sync.prepare()
     if rank == 1:
         p3.grad = torch.full_like(p3, 4.0)
     sync.sync()
-    extra = dict(sym_count=sym_count, any_rank=any_rank, asym_count=sync.asymmetric_steps())
+    lazy_any_rank = None if p3.grad is None else float(p3.grad.mean())
+    extra = dict(sym_count=sym_count, any_rank=any_rank, lazy_any_rank=lazy_any_rank, switched=sync.check_flags,
+                 asym_count=sync.asymmetric_steps())
     q.put((rank, same_after_bcast, as_np(mine), as_np(out), extra))
     dist.barrier()
     dist.destroy_process_group()
@@ -131,11 +135,12 @@ def test_two_rank_flat_allreduce_gloo():
         assert p.exitcode == 0
     (_, b0, mine0, out0, x0), (_, b1, mine1, out1, x1) = res
     assert b0 and b1
-    # flag handling: symmetric steps are not counted; with check_flags a gradient present on ONE rank reaches both (4 / 2 ranks);
-    # without it the step is counted on both ranks
+    # flag handling: with check_flags a gradient present on ONE rank reaches both (4 / 2 ranks); the default mode verifies each
+    # new local pattern once, finds the disagreement, applies the same rule and keeps reading the flags back
     assert x0["sym_count"] == 0 and x1["sym_count"] == 0
     assert x0["any_rank"] == 2.0 and x1["any_rank"] == 2.0
-    assert x0["asym_count"] == 1 and x1["asym_count"] == 1
+    assert x0["lazy_any_rank"] == 2.0 and x1["lazy_any_rank"] == 2.0
+    assert x0["switched"] and x1["switched"] and x0["asym_count"] == 0 and x1["asym_count"] == 0
     n_checked = 0
     for name in out0:
         if mine0[name] is None and mine1[name] is None:
