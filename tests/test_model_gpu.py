@@ -357,7 +357,7 @@ def _full_size_inputs(n, cfg, dev, seed=11):
     return d, o, kw
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
 def test_full_size_permutation_and_repeatability(gpu_device, precision):
     """32768 rays at the bench configuration: rendering is a per-ray function (a permutation of the rays permutes the
     outputs bit-exactly, including through the device-side selection / compaction) and repeatable."""
@@ -523,7 +523,42 @@ def test_full_size_precision_modes_agree(gpu_device):
         assert rel < 1e-4, f"{name} gradient: relative L2 difference {rel:.3e}"
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_full_size_16bit_modes_against_f32(gpu_device):
+    """Bench configuration, 16384 rays: the single-pass 16-bit modes (the bench default) against the exact-fp32 mode on
+    identical inputs.  Their accuracy is that of the operand rounding, so the bounds are their own (measured values are
+    printed): rendered colours, agreement of the fine-sample selection, whole-gradient relative L2 per net."""
+    dev = gpu_device
+    n = 16384
+    res = {}
+    from mc_nerf_amd.model import MC_NeRF_Loss
+    for precision in ("f32", "f16", "bf16"):
+        m, cfg = _full_size_model(dev, precision)
+        d, o, kw = _full_size_inputs(n, cfg, dev, seed=23)
+        gt = torch.rand(n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+        c, f = m.render_rays_train(d, o, 0, 0.5, **kw)
+        MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([c, f, gt]).backward()
+        k = int(m.last_selection[1].item())
+        sel = m.last_selection[0][:k].long()
+        res[precision] = (c.detach(), f.detach(), set((sel[:, 0] * 4096 + sel[:, 1]).tolist()),
+                          torch.cat([p.grad.reshape(-1) for p in m.nerf_coarse.parameters()]),
+                          torch.cat([p.grad.reshape(-1) for p in m.nerf_fine.parameters()]))
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    a = res["f32"]
+    # measured (MI355X): f16 5.7e-6 / 1.8e-6, identical selection, gradients 2.1e-3 / 6.4e-4; bf16 4.7e-5 / 2.4e-5, 0.99997, 5.9e-3 / 1.9e-3
+    # -- the f16 mode renders inside the 1e-4 bar of the exact modes at the bench configuration
+    for precision, tol_rgb, tol_grad in (("f16", 1e-4, 1e-2), ("bf16", 5e-4, 3e-2)):
+        b = res[precision]
+        e_c, e_f = float((a[0] - b[0]).abs().max()), float((a[1] - b[1]).abs().max())
+        common = len(a[2] & b[2]) / max(1, len(a[2] | b[2]))
+        rel = [float((a[i].double() - b[i].double()).norm() / a[i].double().norm()) for i in (3, 4)]
+        print(f"[{precision} vs f32, {n} rays, 8x256] max|rgb_c| {e_c:.2e} max|rgb_f| {e_f:.2e} selection overlap {common:.5f} "
+              f"grad rel L2 coarse {rel[0]:.3e} fine {rel[1]:.3e}")
+        assert e_c < tol_rgb and e_f < tol_rgb
+        assert common > 0.9999
+        assert rel[0] < tol_grad and rel[1] < tol_grad
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
 def test_full_size_cap_path(gpu_device, precision):
     """BASELINE configs[4]-like sampling (64 coarse + 256 fine grid, scale 4) on the full-size nets: more than 128 fine
     samples per ray get selected at random init, so the training cap (model/mc_nerf.py:630-632) binds -- exactly
