@@ -212,6 +212,9 @@ __device__ __forceinline__ void mcn16_ws_store(const V& v, V* p) {
     *p = v;
 #elif defined(ABL16_SINKSTORE)      // (timing only: the value is computed, the store is not issued)
     asm volatile("" ::"v"(v), "v"(p));
+#elif defined(ABL16_STORE_POLICY)   // (experiment: another cache policy on the workspace stores, e.g. -DABL16_STORE_POLICY='"sc0 sc1 nt"')
+    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off " ABL16_STORE_POLICY ::"v"(p), "v"(v) : "memory");
+    else __builtin_nontemporal_store(v, p);
 #else
     __builtin_nontemporal_store(v, p);
 #endif
