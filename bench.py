@@ -41,7 +41,7 @@ B32 = {"fwd": 10 * 1024 + 256 + 128 + 320 + 16 + 8,
 #  16-bit modes: 10 slots x 256 x 2 B (+ encoding 128, sh 64, masks 320, output 16, index 8)
 B16 = {"fwd": 10 * 512 + 128 + 64 + 320 + 16 + 8,
        "bwd": 10 * 512 + 64 + 320 + 64 + 32 + 8,
-       "dw": 2 * 512 * 9 + 2 * (512 + 128) + 2 * (512 + 64)}
+       "dw": 2 * 512 * 8 + (2 * 512 + 128) + (512 + 128) + 2 * (512 + 64)}    # the skip layer reads [hidden | encoded] against its dY in one segment
 DTYPE_TEXT = {"f32": "f32", "f16x3": "f16x3 (split-f16 MFMA operands: 3 MFMAs per product, fp32 accumulate/storage)",
               "f16": "f16 (single-pass f16 MFMA operands, fp32 accumulate, 2-byte workspaces)",
               "bf16": "bf16 (single-pass bf16 MFMA operands, fp32 accumulate, 2-byte workspaces)"}

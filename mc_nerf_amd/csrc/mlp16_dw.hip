@@ -3,7 +3,7 @@
 // over the fragment-major 16-bit workspaces written by mlp16_fwd.hip (X) and mlp16_bwd.hip (dY, scaled by SG).
 // Replaces the dW half of autograd's addmm backward for every nn.Linear of CorseFine_NeRF (model/net_block.py:51-65).
 //
-// HBM-bound streaming kernel, ONE launch per net: the 13 (depth + 5) GEMM segments of a net are laid end to end as one
+// HBM-bound streaming kernel, ONE launch per net: the 12 (depth + 4; depth + 5 for the narrow nets, whose skip layer stays two segments) GEMM segments of a net are laid end to end as one
 // linear sequence of 32-row tiles weighted by their bytes, the sequence is cut into gridDim.x equal pieces and the
 // persistent workgroup (8 waves, one per CU) b streams piece b.  A piece lies inside one segment or crosses one
 // boundary, so a segment's dW block is flushed (fp32 float atomics from the MFMA accumulators) by ~ grid / 13 + 1
@@ -21,7 +21,11 @@
 struct Dw16Seg {
     const char* dY; int ksn;      // fragment-major [tile][ksn][64][8]: N = 16 ksn columns
     const char* X;  int ksk;      // fragment-major [tile][ksk][64][8]: K = 16 ksk columns
-    int n_lo, n_real, k_real;     // outputs n_lo <= n < n_real are real (row n - n_lo of dW); inputs k < k_real
+    const char* X2; int ksk2;     // optional second input block, K2 = 16 ksk2 more columns (the skip layer: [hidden | encoded] in ONE
+                                  // pass, so its dY is read once); null / 0 otherwise
+    int n_lo, n_real;             // outputs n_lo <= n < n_real are real (row n - n_lo of dW)
+    int col, k_real;              // input k < K of X is real for k < k_real and lands in column col + k of the dW row
+    int col2, k_real2;            // input K + k of X2: column col2 + k, real for k < k_real2
     float* dW; int ldw;
     float* db;
 };
@@ -29,8 +33,8 @@ struct Dw16Seg {
 constexpr int dw16_pick(int N, int K, bool want_vn) {
     int bestG = 0, bestVN = 1, bestKT = 1;
     for (int vn = 4; vn >= 1; vn /= 2)
-        for (int kt = 4; kt >= 1; kt /= 2) {
-            if (32 * vn > N || 32 * kt > K) continue;
+        for (int kt = 5; kt >= 1; kt = (kt == 5 ? 4 : kt / 2)) {
+            if (32 * vn > N || 32 * kt > K || K % (32 * kt) != 0) continue;
             const int g = (N / (32 * vn)) * (K / (32 * kt));
             if (g > MCN16_WAVES) continue;
             const bool better = g > bestG || (g == bestG && vn * kt > bestVN * bestKT) || (g == bestG && vn * kt == bestVN * bestKT && vn > bestVN);
@@ -45,10 +49,11 @@ constexpr int dw16_pick(int N, int K, bool want_vn) {
 
 // tiles [t0, t1) of one segment: stream, accumulate, flush.  Leaves no LDS-DMA piece outstanding and every wave past the
 // barrier that follows the last LDS read, so the next segment's run may refill the ring at once.
-template <int N, int K, bool BF>
+template <int N, int K1, int K2, bool BF>
 __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const int t1, const float sgs, char* smem) {
     using T = Mcn16T<BF>;
-    constexpr int KSN = N / 16, KSK = K / 16, P = KSN + KSK;          // 1 KiB pieces per tile
+    constexpr int K = K1 + K2;                                        // the X2 columns follow the X columns
+    constexpr int KSN = N / 16, KSK1 = K1 / 16, KSK2 = K2 / 16, P = KSN + KSK1 + KSK2;   // 1 KiB pieces per tile
     constexpr int PW = (P + MCN16_WAVES - 1) / MCN16_WAVES;           // pieces per wave (the trailing waves may issue PW - 1)
     constexpr int VN = dw16_pick(N, K, true), KT = dw16_pick(N, K, false);
     constexpr int NG = N / (32 * VN), KG = K / (32 * KT), G = NG * KG, MS = MCN16_WAVES / G;
@@ -61,17 +66,19 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
     const int gi = wave % G, ms = wave / G;
     const int nbase = (gi % NG) * 32 * VN, kbase = (gi / NG) * 32 * KT;
 
-    // ---- LDS-DMA pieces of this wave: piece pi = wave + 8 i (dY fragments first, then X fragments)
+    // ---- LDS-DMA pieces of this wave: piece pi = wave + 8 i (dY fragments first, then the X and X2 fragments)
     const unsigned lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem);
     const char* src[PW];
     const int hh = lane >> 5, mm = lane & 31;
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int pi = wave + MCN16_WAVES * i;
-        const bool isY = pi < KSN;
-        const int s = isY ? pi : pi - KSN;
+        const int which = pi < KSN ? 0 : (pi < KSN + KSK1 ? 1 : 2);
+        const int s = which == 0 ? pi : (which == 1 ? pi - KSN : pi - KSN - KSK1);
         const int m_src = mm ^ (4 * (2 * (s & 1) + hh));
-        const char* base = isY ? sg.dY + ((size_t)t0 * KSN + s) * 1024 : sg.X + ((size_t)t0 * KSK + s) * 1024;
+        const char* base = which == 0 ? sg.dY + ((size_t)t0 * KSN + s) * 1024
+                         : which == 1 ? sg.X + ((size_t)t0 * KSK1 + s) * 1024
+                                      : sg.X2 + ((size_t)t0 * KSK2 + s) * 1024;
         src[i] = base + (hh * 32 + m_src) * 16;
     }
     const int np = (P % MCN16_WAVES == 0 || wave < P % MCN16_WAVES) ? PW : PW - 1;      // wave-uniform
@@ -80,7 +87,7 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
         for (int i = 0; i < PW; ++i) {
             const int pi = wave + MCN16_WAVES * i;
             if (i < np) mcn16_dma16_nt(src[i], lds_base + stage * STAGE + pi * 1024);     // read once: non-temporal (6.5 -> 6.06 ms per fine-net call)
-            src[i] += (size_t)(pi < KSN ? KSN : KSK) * 1024;
+            src[i] += (size_t)(pi < KSN ? KSN : (pi < KSN + KSK1 ? KSK1 : KSK2)) * 1024;
         }
     };
 #define DW16_WAIT_ASM(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
@@ -181,15 +188,19 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             const int k = kbase + 32 * kt + r;
+            // (a 32-column tile lies inside X or inside X2: K1 is a multiple of 32)
+            const bool in2 = K2 > 0 && kbase + 32 * kt >= K1;
+            const bool k_ok = in2 ? (k - K1 < sg.k_real2) : (k < sg.k_real);
+            const int colk = in2 ? sg.col2 + (k - K1) : sg.col + k;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
 #if defined(DW16_ABL_NOEPI)       // (timing-only ablations of the accumulator flush)
-                if (n >= sg.n_lo && n < sg.n_real && k < sg.k_real && acc[t][kt][e] == 12345.f) sg.dW[k] = 0.f;
+                if (n >= sg.n_lo && n < sg.n_real && k_ok && acc[t][kt][e] == 12345.f) sg.dW[colk] = 0.f;
 #elif defined(DW16_ABL_WGSCOPE)
-                if (n >= sg.n_lo && n < sg.n_real && k < sg.k_real) __hip_atomic_fetch_add(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + k, acc[t][kt][e] * inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (n >= sg.n_lo && n < sg.n_real && k_ok) __hip_atomic_fetch_add(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + colk, acc[t][kt][e] * inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
-                if (n >= sg.n_lo && n < sg.n_real && k < sg.k_real) atomicAdd(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + k, acc[t][kt][e] * inv);
+                if (n >= sg.n_lo && n < sg.n_real && k_ok) atomicAdd(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + colk, acc[t][kt][e] * inv);
 #endif
             }
         }
@@ -207,12 +218,17 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
 #define DW16_MAXSEG 15
 struct Dw16Job {
     int n;
-    int shape[DW16_MAXSEG];       // 0: W x W   1: W x 64 (encoded-input columns)   2: 32 x W (sh.2 / sigma.2 rows)
+    int shape[DW16_MAXSEG];       // 0: W x W   1: W x 64 (encoded-input columns)   2: 32 x W (sh.2 / sigma.2 rows)   3: W x (W + 64) (skip layer)
     Dw16Seg seg[DW16_MAXSEG];
 };
 
+// the skip layer as ONE segment over [hidden | encoded] inputs (its dY read once): wide nets, where the W x (W + 64) block
+// tiles the 8 waves evenly (2 x 5 tiles of 32 x 32 per wave at W = 256)
+template <int W> struct Dw16SkipMerged { static constexpr bool value = (W == 256); };   // (W + 64 = 192 columns do not tile 8 waves at W = 128)
+
 template <int W, bool BF>
 __global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_stream_kernel(Dw16Job job, const int* count, int rows_cap, const unsigned* gmax_bits) {
+    constexpr bool SKIP_MERGED = Dw16SkipMerged<W>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int rows = count ? min(*count, rows_cap) : rows_cap;
     const int ntiles = (rows + 31) / 32;
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_stream_kernel(Dw16Job j
     const float gmax = gmax_bits ? __uint_as_float(*gmax_bits) : 1.f;
     const float sgs = (gmax > 0.f && gmax < 3e38f) ? exp2f(4.f - ceilf(log2f(gmax))) : 1.f;
     // the linear tile sequence, in units of 1 KiB pieces: segment s holds ntiles tiles of pieces(shape) each
-    auto pieces = [](int shape) { return shape == 0 ? 2 * W / 16 : shape == 1 ? W / 16 + MCN16_ENCKS : 2 + W / 16; };
+    auto pieces = [](int shape) { return shape == 0 ? 2 * W / 16 : shape == 1 ? W / 16 + MCN16_ENCKS : shape == 2 ? 2 + W / 16 : 2 * W / 16 + MCN16_ENCKS; };
     long long total = 0;
     for (int s = 0; s < job.n; ++s) total += (long long)pieces(job.shape[s]) * ntiles;
     const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
@@ -232,9 +248,10 @@ __global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_stream_kernel(Dw16Job j
         const int t0 = (int)(a < 0 ? 0 : a > ntiles ? ntiles : a), t1 = (int)(e < 0 ? 0 : e > ntiles ? ntiles : e);
         base += (long long)P * ntiles;
         if (t0 >= t1) continue;                                        // (block-uniform)
-        if (shape == 0) dw16_run<W, W, BF>(job.seg[s], t0, t1, sgs, smem);
-        else if (shape == 1) dw16_run<W, 16 * MCN16_ENCKS, BF>(job.seg[s], t0, t1, sgs, smem);
-        else dw16_run<32, W, BF>(job.seg[s], t0, t1, sgs, smem);
+        if (shape == 0) dw16_run<W, W, 0, BF>(job.seg[s], t0, t1, sgs, smem);
+        else if (shape == 1) dw16_run<W, 16 * MCN16_ENCKS, 0, BF>(job.seg[s], t0, t1, sgs, smem);
+        else if (shape == 2) dw16_run<32, W, 0, BF>(job.seg[s], t0, t1, sgs, smem);
+        else if constexpr (SKIP_MERGED) dw16_run<W, W, 16 * MCN16_ENCKS, BF>(job.seg[s], t0, t1, sgs, smem);
     }
 }
 
@@ -255,7 +272,7 @@ static hipError_t dw16_launch_job(const Dw16Job& job, const int* count, int rows
     const long long ntiles = (rows_cap + 31) / 32;
     long long grid = dw16_num_cus();
     if (grid > ntiles * job.n) grid = ntiles * job.n;
-    const int pmax = 2 * W / 16 > W / 16 + MCN16_ENCKS ? 2 * W / 16 : W / 16 + MCN16_ENCKS;
+    const int pmax = Dw16SkipMerged<W>::value ? 2 * W / 16 + MCN16_ENCKS : (2 * W / 16 > W / 16 + MCN16_ENCKS ? 2 * W / 16 : W / 16 + MCN16_ENCKS);
     const size_t lds = (size_t)DW16_STAGES * pmax * 1024;
     void (*kern)(Dw16Job, const int*, int, const unsigned*) = bf16 ? dw16_stream_kernel<W, true> : dw16_stream_kernel<W, false>;
     static bool attr_set[2] = {false, false};                          // (per width instantiation and precision)
@@ -279,19 +296,26 @@ hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
     job.n = 0;
     auto add = [&](int shape, const Dw16Seg& s) { job.shape[job.n] = shape; job.seg[job.n] = s; ++job.n; };
     if (D + 5 > DW16_MAXSEG) return hipErrorInvalidValue;
+    const bool merged = (W == 256);                   // (Dw16SkipMerged)
     for (int l = 0; l < D; ++l) {
         const int ldw = mcn_in_features(D, W, L.skip, l);
-        if (l == 0 || l == L.skip)        // encoded-input columns
-            add(1, Dw16Seg{dy(l), KS, enc, MCN16_ENCKS, 0, W, MCN_ENC, a.grads + L.pW[l], ldw, a.grads + L.pB[l]});
-        if (l > 0)                        // hidden-input columns (after the 63 encoded ones at the skip layer)
-            add(0, Dw16Seg{dy(l), KS, act(l - 1), KS, 0, W, W, a.grads + L.pW[l] + (l == L.skip ? MCN_ENC : 0), ldw,
-                           l == L.skip ? nullptr : a.grads + L.pB[l]});
+        float* dWl = a.grads + L.pW[l];
+        float* dbl = a.grads + L.pB[l];
+        if (l == 0)                       // encoded-input columns only
+            add(1, Dw16Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl});
+        else if (l == L.skip && merged)   // [hidden | encoded] in one pass: hidden k -> column 63 + k, encoded k -> column k
+            add(3, Dw16Seg{dy(l), KS, act(l - 1), KS, enc, MCN16_ENCKS, 0, W, MCN_ENC, W, 0, MCN_ENC, dWl, ldw, dbl});
+        else if (l == L.skip) {
+            add(1, Dw16Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl});
+            add(0, Dw16Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, MCN_ENC, W, 0, 0, dWl, ldw, nullptr});
+        } else
+            add(0, Dw16Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, dWl, ldw, dbl});
     }
-    add(0, Dw16Seg{dy(D), KS, act(D - 1), KS, 0, W, W, a.grads + L.pWs1, W, a.grads + L.pBs1});
-    add(0, Dw16Seg{dy(D + 1), KS, act(D - 1), KS, 0, W, W, a.grads + L.pWc1, W, a.grads + L.pBc1});
-    add(2, Dw16Seg{dsh, 2, act(D + 1), KS, 0, MCN_NSH, W, a.grads + L.pWc2, W, a.grads + L.pBc2});
+    add(0, Dw16Seg{dy(D), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWs1, W, a.grads + L.pBs1});
+    add(0, Dw16Seg{dy(D + 1), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWc1, W, a.grads + L.pBc1});
+    add(2, Dw16Seg{dsh, 2, act(D + 1), KS, nullptr, 0, 0, MCN_NSH, 0, W, 0, 0, a.grads + L.pWc2, W, a.grads + L.pBc2});
     // sigma.2 (1 x W): d sigma sits in column 27 of dsh, its input is the sigma hidden layer
-    add(2, Dw16Seg{dsh, 2, act(D), KS, MCN_NSH, MCN_NSH + 1, W, a.grads + L.pWs2, W, a.grads + L.pBs2});
+    add(2, Dw16Seg{dsh, 2, act(D), KS, nullptr, 0, MCN_NSH, MCN_NSH + 1, 0, W, 0, 0, a.grads + L.pWs2, W, a.grads + L.pBs2});
     switch (W) {
         case 256: return dw16_launch_job<256>(job, a.count, a.rows, a.bf16, a.gmax_bits, st);
         case 128: return dw16_launch_job<128>(job, a.count, a.rows, a.bf16, a.gmax_bits, st);
