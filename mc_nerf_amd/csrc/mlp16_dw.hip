@@ -3,7 +3,7 @@
 // over the fragment-major 16-bit workspaces written by mlp16_fwd.hip (X) and mlp16_bwd.hip (dY, scaled by SG).
 // Replaces the dW half of autograd's addmm backward for every nn.Linear of CorseFine_NeRF (model/net_block.py:51-65).
 //
-// HBM-bound streaming kernel, ONE launch per net: the 12 (depth + 4; depth + 5 for the narrow nets, whose skip layer stays two segments) GEMM segments of a net are laid end to end as one
+// HBM-bound streaming kernel, ONE launch per net: the 12 (depth + 4; depth + 5 for the 32- and 64-wide test nets, whose skip layer stays two segments) GEMM segments of a net are laid end to end as one
 // linear sequence of 32-row tiles weighted by their bytes, the sequence is cut into gridDim.x equal pieces and the
 // persistent workgroup (8 waves, one per CU) b streams piece b.  A piece lies inside one segment or crosses one
 // boundary, so a segment's dW block is flushed (fp32 float atomics from the MFMA accumulators) by ~ grid / 13 + 1
@@ -33,7 +33,7 @@ struct Dw16Seg {
 constexpr int dw16_pick(int N, int K, bool want_vn) {
     int bestG = 0, bestVN = 1, bestKT = 1;
     for (int vn = 4; vn >= 1; vn /= 2)
-        for (int kt = 5; kt >= 1; kt = (kt == 5 ? 4 : kt / 2)) {
+        for (int kt = 5; kt >= 1; --kt) {
             if (32 * vn > N || 32 * kt > K || K % (32 * kt) != 0) continue;
             const int g = (N / (32 * vn)) * (K / (32 * kt));
             if (g > MCN16_WAVES) continue;
@@ -224,7 +224,7 @@ struct Dw16Job {
 
 // the skip layer as ONE segment over [hidden | encoded] inputs (its dY read once): wide nets, where the W x (W + 64) block
 // tiles the 8 waves evenly (2 x 5 tiles of 32 x 32 per wave at W = 256)
-template <int W> struct Dw16SkipMerged { static constexpr bool value = (W == 256); };   // (W + 64 = 192 columns do not tile 8 waves at W = 128)
+template <int W> struct Dw16SkipMerged { static constexpr bool value = (W == 256) || (W == 128); };   // (128 x 192: 1 x 3 tiles per wave)
 
 template <int W, bool BF>
 __global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_stream_kernel(Dw16Job job, const int* count, int rows_cap, const unsigned* gmax_bits) {
@@ -296,7 +296,7 @@ hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
     job.n = 0;
     auto add = [&](int shape, const Dw16Seg& s) { job.shape[job.n] = shape; job.seg[job.n] = s; ++job.n; };
     if (D + 5 > DW16_MAXSEG) return hipErrorInvalidValue;
-    const bool merged = (W == 256);                   // (Dw16SkipMerged)
+    const bool merged = (W == 256 || W == 128);       // (Dw16SkipMerged)
     for (int l = 0; l < D; ++l) {
         const int ldw = mcn_in_features(D, W, L.skip, l);
         float* dWl = a.grads + L.pW[l];
