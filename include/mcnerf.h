@@ -241,6 +241,17 @@ int mcnerf_camera_bwd(const float* wpose, const float* wpose_intr, const float* 
 int mcnerf_reproj_loss_fwd(const float* pd, const float* gt, int n, int H, int W, float* loss, void* stream);
 int mcnerf_reproj_loss_bwd(const float* pd, const float* gt, int n, int H, int W, const float* dloss, float* d_pd, void* stream);
 
+/* The whole loss of a NeRF-stage train step, MC_NeRF_Loss.forward with the keys {"intr", "rgb"} (model/loss.py:13-31), value and
+ * gradients in one launch:  total = L_intr / (L_intr + 1e-8) [normalise != 0: the GLOBAL_OPTIM / FINE_TUNE rescaling of :20-23, its
+ * denominator a detached constant; normalise == 0: L_intr itself] + mean((rgb_c - gt)^2) + mean((rgb_f - gt)^2) [rgb_f may be null:
+ * coarse only, :37-41].  pd, pt_gt [np,2] pixels (np may be 0), rgb_*, gt [nrgb] floats (nrgb = 3 N).
+ * out[3] = {total, L_intr, rgb term};  d_pd [np,2], d_c, d_f [nrgb] = d total / d input.
+ * mcnerf_scale3: a, b, c (c may be null) *= *g in place -- the saved gradients times the upstream gradient of the total. */
+int mcnerf_train_loss(const float* pd, const float* pt_gt, int np, int H, int W, int normalise,
+                      const float* rgb_c, const float* rgb_f, const float* gt, int nrgb,
+                      float* out, float* d_pd, float* d_c, float* d_f, void* stream);
+int mcnerf_scale3(float* a, int na, float* b, int nb, float* c, int nc, const float* g, void* stream);
+
 /* Fused multi-tensor Rectified-Adam step (one launch for all tensors of a param group).
  * Replaces the per-tensor loop of RAdam.step (model/net_utils.py:38-99).  The arrays of n_tensors device
  * pointers / sizes live on the HOST; step_size and `rectified` (N_sma >= 5) are the host-side scalars of the

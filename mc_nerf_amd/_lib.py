@@ -36,6 +36,8 @@ SIGNATURES = {
     "mcnerf_mlp_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
     "mcnerf_encode": (_I, [_P, _P, _I, _P, _P]),
     "mcnerf_upload_f32": (_I, [_P, _P, _I, _P]),
+    "mcnerf_train_loss": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "mcnerf_scale3": (_I, [_P, _I, _P, _I, _P, _I, _P, _P]),
     "mcnerf_sample_perm": (_I, [_P, ctypes.c_longlong, _I, _P, _P]),
     "mcnerf_mlp_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "mcnerf_mlp_fwd_f16x3": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),

@@ -103,6 +103,17 @@ int mcnerf_sample_perm(int64_t* out, long long n, int batch, const uint32_t* see
     return check("mcnerf_sample_perm", mcn_launch_sample_perm((long long*)out, n, batch, seed, (hipStream_t)stream));
 }
 
+int mcnerf_train_loss(const float* pd, const float* pt_gt, int np, int H, int W, int normalise,
+                      const float* rgb_c, const float* rgb_f, const float* gt, int nrgb,
+                      float* out, float* d_pd, float* d_c, float* d_f, void* stream) {
+    REQ(np >= 0 && (np == 0 || (pd && pt_gt && d_pd)) && rgb_c && gt && nrgb > 0 && out && d_c && (!rgb_f || d_f) && H > 0 && W > 0, "mcnerf_train_loss");
+    return check("mcnerf_train_loss", mcn_launch_train_loss(pd, pt_gt, np, H, W, normalise, rgb_c, rgb_f, gt, nrgb, out, d_pd, d_c, d_f, (hipStream_t)stream));
+}
+int mcnerf_scale3(float* a, int na, float* b, int nb, float* c, int nc, const float* g, void* stream) {
+    REQ(g && na >= 0 && nb >= 0 && nc >= 0 && (na == 0 || a) && (nb == 0 || b), "mcnerf_scale3");
+    return check("mcnerf_scale3", mcn_launch_scale3(a, na, b, nb, c, c ? nc : 0, g, (hipStream_t)stream));
+}
+
 int mcnerf_upload_f32(float* dst, const float* host_vals, int n, void* stream) {
     REQ(dst && host_vals && n >= 0 && n <= 16, "mcnerf_upload_f32");
     return check("mcnerf_upload_f32", mcn_launch_upload_f32(dst, host_vals, n, (hipStream_t)stream));

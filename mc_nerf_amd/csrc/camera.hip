@@ -240,6 +240,68 @@ hipError_t mcn_launch_reproj_loss_bwd(const float* pd, const float* gt, int n, i
     return hipGetLastError();
 }
 
+// ---- the whole loss of a NeRF-stage train step (model/loss.py:13-31 with the GLOBAL_OPTIM / FINE_TUNE keys {"intr", "rgb"}):
+//   total = L_intr / (L_intr + 1e-8)  [the value-1 normalisation of :20-23; its denominator is a detached constant]
+//         + mean((rgb_c - gt)^2) + mean((rgb_f - gt)^2)
+// and its gradients wrt the reprojected pixels and the two renders, in ONE launch of one workgroup (two block reductions,
+// then the gradient pass): ~ 10 tiny elementwise / reduce launches of the eager formulation each way.  out[0] = total,
+// out[1] = L_intr, out[2] = the rgb term.
+__global__ __launch_bounds__(1024) void train_loss_kernel(const float* pd, const float* ptg, int np, float inv_w2, float inv_h2, int normalise,
+                                                         const float* rgb_c, const float* rgb_f, const float* gt, int nrgb,
+                                                         float* out, float* d_pd, float* d_c, float* d_f) {
+    __shared__ float red[2][1024];
+    const int t = threadIdx.x;
+    float ai = 0.f, ar = 0.f;
+    for (int i = t; i < np; i += 1024) {
+        const float ex = pd[2 * i] - ptg[2 * i], ey = pd[2 * i + 1] - ptg[2 * i + 1];
+        ai += ex * ex * inv_w2 + ey * ey * inv_h2;
+    }
+    for (int i = t; i < nrgb; i += 1024) {
+        const float g = gt[i], ec = rgb_c[i] - g;
+        ar += ec * ec;
+        if (rgb_f) { const float ef = rgb_f[i] - g; ar += ef * ef; }
+    }
+    red[0][t] = ai; red[1][t] = ar;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (t < s) { red[0][t] += red[0][t + s]; red[1][t] += red[1][t + s]; }
+        __syncthreads();
+    }
+    const float li = np > 0 ? red[0][0] / (float)np : 0.f, lr = red[1][0] / (float)nrgb;
+    const float si = normalise ? 1.0f / (li + 1e-8f) : 1.0f;       // d total / d L_intr
+    if (t == 0) { out[0] = li * si + lr; out[1] = li; out[2] = lr; }
+    const float gi = si * 2.f / (float)(np > 0 ? np : 1), gr = 2.f / (float)nrgb;
+    for (int i = t; i < np; i += 1024) {
+        d_pd[2 * i] = gi * (pd[2 * i] - ptg[2 * i]) * inv_w2;
+        d_pd[2 * i + 1] = gi * (pd[2 * i + 1] - ptg[2 * i + 1]) * inv_h2;
+    }
+    for (int i = t; i < nrgb; i += 1024) {
+        const float g = gt[i];
+        d_c[i] = gr * (rgb_c[i] - g);
+        if (rgb_f) d_f[i] = gr * (rgb_f[i] - g);
+    }
+}
+// in place: the saved gradients times the upstream scalar (1 for loss.backward())
+__global__ __launch_bounds__(256) void scale3_kernel(float* a, int na, float* b, int nb, float* c, int nc, const float* g) {
+    const float s = *g;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a[i] *= s;
+    if (i < nb) b[i] *= s;
+    if (c && i < nc) c[i] *= s;
+}
+hipError_t mcn_launch_train_loss(const float* pd, const float* ptg, int np, int H, int W, int normalise, const float* rgb_c, const float* rgb_f,
+                                 const float* gt, int nrgb, float* out, float* d_pd, float* d_c, float* d_f, hipStream_t st) {
+    hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(1024), 0, st, pd, ptg, np, 1.0f / ((float)W * (float)W), 1.0f / ((float)H * (float)H),
+                       normalise, rgb_c, rgb_f, gt, nrgb, out, d_pd, d_c, d_f);
+    return hipGetLastError();
+}
+hipError_t mcn_launch_scale3(float* a, int na, float* b, int nb, float* c, int nc, const float* g, hipStream_t st) {
+    const int n = na > nb ? (na > nc ? na : nc) : (nb > nc ? nb : nc);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scale3_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, na, b, nb, c, nc, g);
+    return hipGetLastError();
+}
+
 hipError_t mcn_launch_camera_fwd(const McnCameraArgs& a, hipStream_t st) {
     if (a.C <= 0) return hipSuccess;
     hipLaunchKernelGGL(camera_fwd_kernel, dim3((a.C + 63) / 64), dim3(64), 0, st, a);

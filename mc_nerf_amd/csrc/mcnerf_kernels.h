@@ -25,6 +25,9 @@ struct McnMlpFwdArgs {
 };
 hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, float* out, hipStream_t st);
 hipError_t mcn_launch_sample_perm(long long* out, long long n, int batch, const unsigned* seed, hipStream_t st);
+hipError_t mcn_launch_train_loss(const float* pd, const float* ptg, int np, int H, int W, int normalise, const float* rgb_c, const float* rgb_f,
+                                 const float* gt, int nrgb, float* out, float* d_pd, float* d_c, float* d_f, hipStream_t st);
+hipError_t mcn_launch_scale3(float* a, int na, float* b, int nb, float* c, int nc, const float* g, hipStream_t st);
 hipError_t mcn_launch_upload_f32(float* dst, const float* host_vals, int n, hipStream_t st);
 hipError_t mcn_launch_mlp_fwd(const McnMlpFwdArgs& a, hipStream_t st);
 hipError_t mcn_launch_mlp_fwd_h(const McnMlpFwdArgs& a, hipStream_t st);     // split-f16 mode: a.packed = mcn_launch_pack_h output

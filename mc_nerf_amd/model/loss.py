@@ -17,6 +17,13 @@ class MC_NeRF_Loss(nn.Module):
 
     def forward(self, loss_dict, epoch_type):
         self.global_step += 1
+        if set(loss_dict) == {"intr", "rgb"} and loss_dict["rgb"][0].is_cuda:
+            # the NeRF stages: reprojection term (rescaled to value 1 outside the camera-only stage, :20-23) + both rgb terms,
+            # value and gradients in one launch (csrc/camera.hip: train_loss_kernel)
+            from .render import TrainLossFn
+            pd, pt_gt = loss_dict["intr"]
+            rgb_c, rgb_f, gt = loss_dict["rgb"]
+            return TrainLossFn.apply(pd, pt_gt.to(pd.device), rgb_c, rgb_f, gt, self.img_h, self.img_w, epoch_type != "CAM_PARAM_EPOCH")
         total = 0.0
         if "intr" in loss_dict:
             l_intr = self.get_reproject_loss(loss_dict["intr"])

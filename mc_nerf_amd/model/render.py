@@ -233,6 +233,27 @@ class CameraFn(torch.autograd.Function):
         return tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[:6])) + (None, None, None, None)
 
 
+class TrainLossFn(torch.autograd.Function):
+    """MC_NeRF_Loss.forward (model/loss.py:13-31) for the NeRF stages' keys {"intr", "rgb"} as ONE launch: value and every
+    gradient; backward scales the saved gradients by the upstream scalar (one launch)."""
+
+    @staticmethod
+    def forward(ctx, pd, pt_gt, rgb_c, rgb_f, gt, H, W, normalise):
+        cf = lambda t: None if t is None else t.contiguous().float()
+        pd, pt_gt, rgb_c, rgb_f, gt = cf(pd), cf(pt_gt), cf(rgb_c), cf(rgb_f), cf(gt)
+        out, d_pd, d_c, d_f = ops.train_loss(pd, pt_gt, H, W, normalise, rgb_c, rgb_f, gt)
+        ctx.grads = (d_pd, d_c, d_f)
+        ctx.parts = out
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d_pd, d_c, d_f = ctx.grads
+        ops.scale3_(d_pd, d_c, d_f, g.contiguous().float().reshape(1))
+        ctx.grads = None
+        return d_pd, None, d_c, d_f, None, None, None, None
+
+
 class ReprojLossFn(torch.autograd.Function):
     """MC_NeRF_Loss.get_reproject_loss (model/loss.py:45-58) as one kernel each way."""
 

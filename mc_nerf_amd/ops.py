@@ -380,6 +380,24 @@ def reproj_loss_bwd(pd: Tensor, gt: Tensor, H: int, W: int, dloss: Tensor) -> Te
     return d
 
 
+def train_loss(pd: Optional[Tensor], pt_gt: Optional[Tensor], H: int, W: int, normalise: bool, rgb_c: Tensor, rgb_f: Optional[Tensor], gt: Tensor):
+    """MC_NeRF_Loss.forward for the keys {"intr", "rgb"} in one launch: -> out [3] = (total, L_intr, rgb term), d_pd | None, d_c, d_f | None."""
+    dev = rgb_c.device
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    np_ = pd.numel() // 2 if pd is not None else 0
+    d_pd = torch.empty_like(pd) if pd is not None else None
+    d_c = torch.empty_like(rgb_c)
+    d_f = torch.empty_like(rgb_f) if rgb_f is not None else None
+    _lib.call("mcnerf_train_loss", _p(pd), _p(pt_gt), np_, int(H), int(W), int(bool(normalise)), _p(rgb_c), _p(rgb_f), _p(gt), rgb_c.numel(),
+              _p(out), _p(d_pd), _p(d_c), _p(d_f), _stream())
+    return out, d_pd, d_c, d_f
+
+
+def scale3_(a: Optional[Tensor], b: Tensor, c: Optional[Tensor], g: Tensor):
+    """a, b, c *= g (device scalar) in place, one launch."""
+    _lib.call("mcnerf_scale3", _p(a), a.numel() if a is not None else 0, _p(b), b.numel(), _p(c), c.numel() if c is not None else 0, _p(g), _stream())
+
+
 def gather_gt(image_u8: Tensor, pix: Tensor) -> Tensor:
     """image_u8 [H*W, 3|4] uint8 on the device, pix [n] int64 -> [n,3] fp32 (RGBA blended on white)."""
     n = pix.numel()

@@ -551,3 +551,32 @@ def test_upload_f32_passes_host_values_bit_exactly(gpu_device):
         assert torch.equal(out.cpu().view(torch.int32), hv.view(torch.int32))
     emb_w = torch.tensor([1.0, 1.0, 0.75, 0.25, 0, 0, 0, 0, 0, 0])
     assert torch.equal(ops.upload_f32(emb_w, gpu_device).cpu(), emb_w)
+
+
+@pytest.mark.parametrize("normalise", [True, False])
+@pytest.mark.parametrize("with_fine", [True, False])
+def test_fused_train_loss_matches_eager_formulation(gpu_device, normalise, with_fine):
+    """mcnerf_train_loss / TrainLossFn = MC_NeRF_Loss.forward for the keys {"intr", "rgb"} (model/loss.py:13-31): value and the
+    gradients wrt the reprojected pixels and both renders against the eager torch formulation, incl. an upstream factor."""
+    from mc_nerf_amd.model.render import TrainLossFn
+    dev = gpu_device
+    g = torch.Generator().manual_seed(3)
+    H, W, n = 800, 600, 7001
+    pd = (torch.rand(110, 5, 2, generator=g) * 700).to(dev).requires_grad_(True)
+    ptg = (torch.rand(110, 5, 2, generator=g) * 700).to(dev)
+    rc = torch.rand(n, 3, generator=g).to(dev).requires_grad_(True)
+    rf = torch.rand(n, 3, generator=g).to(dev).requires_grad_(True) if with_fine else None
+    gt = torch.rand(n, 3, generator=g).to(dev)
+    total = TrainLossFn.apply(pd, ptg, rc, rf, gt, H, W, normalise)
+    (total * 0.37).backward()
+    got = [pd.grad.clone(), rc.grad.clone(), rf.grad.clone() if with_fine else None]
+    for t in (pd, rc) + ((rf,) if with_fine else ()):
+        t.grad = None
+    F = torch.nn.functional
+    li = F.mse_loss(pd[..., 0] / W, ptg[..., 0] / W) + F.mse_loss(pd[..., 1] / H, ptg[..., 1] / H)
+    ref = (li / (li.detach() + 1e-8) if normalise else li) + F.mse_loss(rc, gt) + (F.mse_loss(rf, gt) if with_fine else 0.0)
+    (ref * 0.37).backward()
+    assert abs(float(total) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    for a, b in zip(got, [pd.grad, rc.grad, rf.grad if with_fine else None]):
+        if b is not None:
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12
