@@ -127,8 +127,8 @@ class RenderTrainFn(torch.autograd.Function):
         dev = rays_d.device
         N = rays_d.shape[0]
         want_rays = ctx.needs_input_grad[10] or ctx.needs_input_grad[11]
-        d_o = torch.zeros(N, 3, dtype=torch.float32, device=dev) if want_rays else None
-        d_d = torch.zeros(N, 3, dtype=torch.float32, device=dev) if want_rays else None
+        d_od = torch.zeros(2, N, 3, dtype=torch.float32, device=dev) if want_rays else None      # (one fill for both)
+        d_o, d_d = (d_od[0], d_od[1]) if want_rays else (None, None)
         # gradient buffers: slices of the step-level arena when a FlatGradSync provided one (so the whole
         # step's gradient is one contiguous all-reduce message), otherwise fresh zeroed buffers
         arena = getattr(owner, "grad_arena", None)

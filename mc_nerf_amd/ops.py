@@ -142,8 +142,8 @@ def raygen_fwd(pose: Tensor, kinv: Tensor, pix: Tensor, W: int) -> Tuple[Tensor,
 
 
 def raygen_bwd(pose: Tensor, kinv: Tensor, pix: Tensor, W: int, d_d: Tensor, d_o: Tensor) -> Tuple[Tensor, Tensor]:
-    d_pose = torch.zeros(3, 4, dtype=torch.float32, device=pix.device)
-    d_kinv = torch.zeros(3, 3, dtype=torch.float32, device=pix.device)
+    z = torch.zeros(24, dtype=torch.float32, device=pix.device)          # (one fill for both accumulation targets)
+    d_pose, d_kinv = z[:12].view(3, 4), z[12:21].view(3, 3)
     _lib.call("mcnerf_raygen_bwd", _p(pose), _p(kinv), _p(pix, torch.int64), pix.numel(), W,
               _p(d_d), _p(d_o), _p(d_pose), _p(d_kinv), _stream())
     return d_pose, d_kinv
