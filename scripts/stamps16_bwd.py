@@ -3,13 +3,11 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import mcnerf_oracle as O
 from mc_nerf_amd import ops, _lib
+from _nets import make_net
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16"
 dev = torch.device("cuda:0")
-nc = O.NetCfg(8, 256, (4,)); net = ops.Net(8, 256, 4)
-p = O.init_params(nc, 7)
-flat = ops.flatten_params(net, [p[k].to(dev) for k in net.names()], dev)
+net, flat = make_net(256, dev)
 N, S = 25600, 128
 g = torch.Generator(device=dev).manual_seed(0)
 o = torch.nn.functional.normalize(torch.randn(N, 3, device=dev, generator=g), dim=-1) * 3

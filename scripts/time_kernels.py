@@ -3,17 +3,14 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import mcnerf_oracle as O
 from mc_nerf_amd import ops
+from _nets import make_net
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 25600
 width = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 S = 128
 dev = torch.device("cuda:0")
-nc = {256: O.NetCfg(8, 256, (4,)), 128: O.NetCfg(4, 128, (2,))}[width]
-net = ops.Net(nc.depth, nc.width, nc.skips[0])
-p = O.init_params(nc, 7)
-flat = ops.flatten_params(net, [p[k].to(dev) for k in net.names()], dev)
+net, flat = make_net(width, dev)
 g = torch.Generator(device=dev).manual_seed(0)
 o = torch.nn.functional.normalize(torch.randn(N, 3, device=dev, generator=g), dim=-1) * 3
 d = torch.nn.functional.normalize(-o + 0.5 * torch.randn(N, 3, device=dev, generator=g), dim=-1)
