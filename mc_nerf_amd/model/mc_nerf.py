@@ -144,20 +144,22 @@ class NeRF_Model(nn.Module):
         """One pass of one net on given samples -> (rgb [N,3], sigmas [N,S], xyz, depth [N,1], opacity [N,1]), the
         reference's `inference` (:682-727) for callers that use it directly.
 
-        The HIP kernels generate the positions themselves from (origin, direction, z grid + per-ray jitter), so
-        `z_vals` must have the reference's structure (its own call sites always do): `z_vals[n, j] = grid[j] + jitter[n]`
-        with `grid` this model's coarse or fine grid; the origins are recovered from `xyz[:, 0]`.  Forward only: training
-        differentiates through the fused `render_rays_train`.  `eps` is the N(0,1) draw of `sigma2weights` (drawn from
-        the device generator when not given)."""
+        The fused HIP kernels generate the positions themselves from (origin, direction, z grid + per-ray jitter).  When
+        `z_vals` has the reference's structure (its own call sites always do): `z_vals[n, j] = grid[j] + jitter[n]` with
+        `grid` this model's coarse or fine grid, that path is taken and the origins are recovered from `xyz[:, 0]`.  Any
+        other `xyz` / `z_vals` goes through the stand-alone kernels on the given positions (`_inference_general`).
+        Forward only: training differentiates through the fused `render_rays_train`.  `eps` is the N(0,1) draw of
+        `sigma2weights` (drawn from the device generator when not given)."""
         N, S_ = z_vals.shape
         dev = rays_d.device
-        grid = self.z_vals_c if S_ == self.samples_c else self.z_vals_f
-        if S_ not in (self.samples_c, self.samples_f):
-            raise NotImplementedError("inference(): z_vals must be this model's coarse or fine grid (+ per-ray jitter)")
         z_vals = z_vals.float()
-        jitter = (z_vals[:, 0] - grid[0]).contiguous()
-        if not torch.allclose(z_vals, grid.unsqueeze(0) + jitter.unsqueeze(1), atol=1e-5, rtol=0):
-            raise NotImplementedError("inference(): z_vals is not grid + per-ray jitter")
+        structured = S_ in (self.samples_c, self.samples_f)
+        if structured:
+            grid = self.z_vals_c if S_ == self.samples_c else self.z_vals_f
+            jitter = (z_vals[:, 0] - grid[0]).contiguous()
+            structured = bool(torch.allclose(z_vals, grid.unsqueeze(0) + jitter.unsqueeze(1), atol=1e-5, rtol=0))
+        if not structured:
+            return self._inference_general(model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render, eps)
         rays_d = rays_d.float().contiguous()
         rays_o = (xyz.reshape(N, S_, 3)[:, 0].float() - rays_d * z_vals[:, :1]).contiguous()
         st = self.settings
@@ -179,6 +181,45 @@ class NeRF_Model(nn.Module):
         rgb, depth, opacity, _, _ = ops.composite_fwd(out, rays_d, grid, jitter, self._dev(eps).float().contiguous(), None,
                                                       st.white_back, want_depth=True)
         return rgb, out[..., 0], xyz, depth, opacity
+
+    @torch.no_grad()
+    def _inference_general(self, model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render, eps):
+        """`inference` on arbitrary sample positions (reference :682-727 literally): encode the given `xyz` and run the net
+        with the stand-alone exact-fp32 kernels (`mcnerf_encode`, `mcnerf_mlp_apply`), scatter into the defaults
+        (sigma_default, white) when an index list is given, then both composites in tensor ops (:705-725)."""
+        st = self.settings
+        N, S_ = z_vals.shape
+        dev = rays_d.device
+        rays_d = rays_d.float().contiguous()
+        xyz3 = xyz.reshape(N, S_, 3).float()
+        flat = model.flat_params()
+        packed = ops.pack_weights(model.net, flat, precision="f32")
+        barf_w = embedding_xyz.barf_weights_on(step_r, dev)
+        if idx_render is None:
+            x = xyz3.reshape(-1, 3).contiguous()
+            dirs = rays_d.unsqueeze(1).expand(-1, S_, -1).reshape(-1, 3).contiguous()
+            out = ops.mlp_apply(model.net, flat, packed, ops.encode(x, barf_w), dirs).reshape(N, S_, 4)
+        else:
+            r, j = idx_render[:, 0].long().to(dev), idx_render[:, 1].long().to(dev)
+            out = torch.ones(N, S_, 4, dtype=torch.float32, device=dev)
+            out[..., 0] = st.sigma_default
+            if r.numel():
+                raw = ops.mlp_apply(model.net, flat, packed, ops.encode(xyz3[r, j].contiguous(), barf_w), rays_d[r].contiguous())
+                out[r, j] = raw
+        if eps is None:
+            eps = torch.randn(N, S_, device=dev)
+        sig, rgbs = out[..., 0], out[..., 1:]
+        deltas = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full_like(z_vals[:, :1], 1e10)], -1)
+        sd = torch.nn.functional.softplus(sig) * (deltas * rays_d.norm(dim=-1, keepdim=True))
+        alpha = 1.0 - torch.exp(-sd)
+        T = torch.exp(-torch.cat([torch.zeros_like(sd[:, :1]), sd[:, :-1]], 1).cumsum(1))
+        prob = T * alpha
+        opacity, depth = prob.sum(1, keepdim=True), (z_vals * prob).sum(1, keepdim=True)
+        w = self.sigma2weights(deltas, sig, self._dev(eps).float())
+        rgb = (w.unsqueeze(-1) * rgbs).sum(1)
+        if st.white_back:
+            rgb = rgb + 1.0 - w.sum(1, keepdim=True)
+        return rgb, sig, xyz, depth, opacity
 
     @staticmethod
     def sigma2weights(deltas, sigmas, eps=None):

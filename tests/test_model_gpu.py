@@ -494,8 +494,17 @@ def test_inference_and_sigma2weights_api(gpu_device, precision):
         assert got[2].shape == xyz.shape
     dl, sg, ep = torch.rand(7, 16) + 0.05, torch.randn(7, 16) * 3, torch.randn(7, 16)
     assert err(m.sigma2weights(dl.to(dev), sg.to(dev), ep.to(dev)), O.sigma2weights(dl, sg, ep).numpy()) < 2e-6
-    with pytest.raises(NotImplementedError):
-        m.inference(m.nerf_coarse, m.emmbedding_xyz, 1.0, xyz.to(dev)[:, :7], d.to(dev), torch.rand(n, 7, device=dev))
+    # arbitrary sample positions (not grid + jitter, a sample count of its own): the general path on the stand-alone kernels
+    g7 = torch.Generator().manual_seed(9)
+    z7 = torch.sort(1.0 + 7.0 * torch.rand(n, 7, generator=g7), dim=1).values
+    xyz7 = o.unsqueeze(1) + d.unsqueeze(1) * z7.unsqueeze(2)
+    e7 = torch.randn(n, 7, generator=g7)
+    for idx in (None, torch.nonzero(torch.rand(n, 7, generator=g7) < 0.5)):
+        rgb, sig, depth, opac, _ = O.inference(pc, cfg.coarse, cfg, 0.5, o, d, z7, e7, idx)
+        got = m.inference(m.nerf_coarse, m.emmbedding_xyz, 0.5, xyz7.to(dev), d.to(dev), z7.to(dev),
+                          None if idx is None else idx.to(dev), True, eps=e7.to(dev))
+        assert err(got[0], rgb.numpy()) < TOL and err(got[3], depth.numpy()) < TOL and err(got[4], opac.numpy()) < TOL
+        assert err(got[1], sig.numpy()) < 1e-4 * max(1.0, float(sig.abs().max()))
 
 
 def test_full_size_precision_modes_agree(gpu_device):
