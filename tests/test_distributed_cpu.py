@@ -195,3 +195,69 @@ def test_prepare_drops_stale_grads_no_doubling():
     for n, p in model.named_parameters():
         if n in first:
             assert torch.allclose(p.grad, first[n], rtol=0, atol=1e-7), n      # same step twice: same gradient, not 2x
+
+
+def _ddp_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        torch.set_num_threads(1)
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from mc_nerf_amd import distributed as D
+        from mc_nerf_amd import synthetic as S
+        from mc_nerf_amd.model import MC_NeRF_Loss
+        D.init_distributed(backend="gloo")
+        model, sp = _build_model()
+        S.init_cameras_near_gt(model, noise=0.01, seed=rank)       # ranks start different: DDP's constructor broadcasts rank 0's
+        calib = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0])
+        ddp = DDP(model, find_unused_parameters=True)              # exactly main.py:61
+        same = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        ref = same.clone()
+        dist.broadcast(ref, src=0)
+        cam = D.shard_cameras(model.train_numb, 0, rank, world, seed=1)[0]
+        local = _stage1_grads(model, sp, cam, calib)               # this rank's own gradients (plain module call, no reducer)
+        for p in model.parameters():
+            p.grad = None
+        wpts, pts = calib
+        data = (torch.zeros(1, 256, 3), torch.tensor([cam]), wpts, pts, wpts, pts)
+        loss_dict, *_ = ddp(data, 0, "CAM_PARAM_EPOCH", 0.0)       # main.py:82 through the DDP wrapper
+        MC_NeRF_Loss(sp)(loss_dict, "CAM_PARAM_EPOCH").backward()
+        out = {n: (None if p.grad is None else p.grad.numpy().copy()) for n, p in model.named_parameters()}
+        keys = list(ddp.state_dict().keys())
+        q.put((rank, bool(torch.equal(same, ref)), {k: (None if v is None else v.numpy().copy()) for k, v in local.items()}, out, keys))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None, None))
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_stock_ddp_wrapper_camera_stage_gloo():
+    """The reference wraps MC_Model in torch's DistributedDataParallel(find_unused_parameters=True) (main.py:61).  The
+    parameters here are views into flat buffers; this checks on two gloo ranks that the stock wrapper accepts them:
+    constructor broadcast, a camera-stage step through `ddp(...)`, DDP's averaged gradients == the mean of the ranks' own,
+    and the "module."-prefixed state-dict keys the reference's checkpoints carry."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for r in res:
+        assert r[1] != "error", r[2]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, l0, o0, k0), (_, b1, l1, o1, k1) = res
+    assert b0 and b1
+    assert all(k.startswith("module.") for k in k0) and any(k.startswith("module.nerf.nerf_fine.") for k in k0)
+    n = 0
+    for name in o0:
+        if l0[name] is None and l1[name] is None:
+            continue                                             # untouched by the stage (DDP leaves zeros or None)
+        mean = (l0[name] + l1[name]) / 2
+        assert abs(o0[name] - mean).max() <= 1e-6 and (o0[name] == o1[name]).all(), name
+        n += 1
+    assert n >= 6                                               # the six camera parameter tensors
