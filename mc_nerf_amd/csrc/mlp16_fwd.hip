@@ -172,7 +172,7 @@ template <int W, bool SAVE, bool BF>
 __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16FwdArgs a) {
     using T = Mcn16T<BF>;
     using SM = Fwd16Smem<W>;
-    constexpr int NT = W / 32, KS = W / 16, MW = W >= 64 ? W / 64 : 1;
+    constexpr int KS = W / 16, MW = W >= 64 ? W / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, h = lane >> 5;
