@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 mcn16_before_mfma<KS>(ring, smem, cur, s);
-                const u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + cur.cur + s * 1024 + lane * 16);
+                const u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + cur.cur + (s & (MCN16_SLAB - 1)) * 1024 + lane * 16);
                 acc = T::mfma(af, xa[s], acc);
             }
         }
