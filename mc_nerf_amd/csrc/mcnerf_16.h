@@ -227,7 +227,9 @@ __device__ __forceinline__ void mcn16_ws_store(const V& v, V* p) {
 // A slab is synchronised EARLY, MCN16_PF fragments before the previous slab ends, so that the A-fragment prefetch
 // (MCN16_PF fragments ahead of the MFMAs) runs straight across slab boundaries: with RING = 8 and AHEAD <= 6 the slot
 // refilled at that point belongs to a slab every wave has already left.
-#define MCN16_PF 4
+#ifndef MCN16_PF
+#define MCN16_PF 2      // (measured 1 / 2 / 3 / 4 / 6 / 8: the backward, which is short of registers, is 2 % faster at 1-2 than at 4; the forwards do not care)
+#endif
 struct Mcn16Ring {
     const char* src;          // packed stream + this lane's byte offset inside a slab (piece PPW * wave, lane * 16)
     unsigned lds_piece;       // LDS byte offset of this wave's first piece inside a slab (wave-uniform)
