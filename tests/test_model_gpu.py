@@ -333,6 +333,29 @@ def test_two_ranks_share_one_gpu_data_parallel(gpu_device):
     assert r.returncode == 0 and "check: OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_bench_two_ranks_share_one_gpu(gpu_device):
+    """`python bench.py --gpus 2` end to end on the one-GPU box: the parent starts two rank processes, they rendezvous (gloo here:
+    RCCL needs one GPU per rank), shard the cameras, run the step loop with the gradient sync, and rank 0 prints the JSON line with
+    the multi-rank fields -- parameters bit-identical across ranks, no asymmetric gradient step, the all-reduce time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCNERF_SHARE_GPU="1", MCNERF_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rays", "2048", "--steps", "6", "--warmup", "2",
+                        "--also=", "--no-cpu-baseline"], capture_output=True, text=True, timeout=580, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "weak"
+    assert j["params_identical_across_ranks"] is True and j["asymmetric_grad_steps"] == 0 and j["finite"] is True
+    assert j["allreduce_ms"] > 0 and j["value"] > 0
+    assert j["config"]["rays_per_step_per_gpu"] == 2048 and j["config"]["parallelism"].startswith("dp2")
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Full-size (BASELINE configs[1]: 64 + 128 samples, coarse 4x128 + fine 8x256) property tests: sizes the CPU oracle
 # cannot finish, checked through properties that do not depend on the size.
