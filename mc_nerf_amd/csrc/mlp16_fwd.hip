@@ -135,9 +135,15 @@ __device__ __forceinline__ void mcn16_layer(Mcn16Ring& ring, char* smem, int lan
         for (int s = 0; s < KTOT; ++s) {
             const int f = t * KTOT + s;
             mcn16_before_mfma<F>(ring, smem, cur, f);
+#ifdef ABL16_HALFLDS      // (timing-only: every second A fragment is not read, its MFMA reuses the previous one -- what half the LDS reads would buy)
+            const u32x4_t a_now = af[(f & ~1) % MCN16_PF];
+            if (f + MCN16_PF < F && ((f + MCN16_PF) & 1) == 0)
+                af[f % MCN16_PF] = *reinterpret_cast<const u32x4_t*>(smem + mcn16_frag_off(ring, cur, f, f + MCN16_PF) + lane * 16);
+#else
             const u32x4_t a_now = af[f % MCN16_PF];
             if (f + MCN16_PF < F)
                 af[f % MCN16_PF] = *reinterpret_cast<const u32x4_t*>(smem + mcn16_frag_off(ring, cur, f, f + MCN16_PF) + lane * 16);
+#endif
             if (t > 0 && s >= START) {
 #pragma unroll
                 for (int i = (s - START) * SPS; i < (s - START + 1) * SPS; ++i)
