@@ -124,7 +124,7 @@ class NeRF_Model(nn.Module):
         return rgb_c, rgb_f
 
     @torch.no_grad()
-    def render_rays_test(self, rays_d, rays_o, model_coarse, model_fine, *, eps_c=None, eps_sel=None, eps_f=None):
+    def render_rays_test(self, rays_d, rays_o, model_coarse, model_fine, *, eps_c=None, eps_sel=None, eps_f=None, _prepared=None):
         """Reference :648-680 (the nets are arguments because valid_train passes freshly loaded ones)."""
         N, dev = rays_d.shape[0], rays_d.device
         if N == 0:
@@ -136,7 +136,7 @@ class NeRF_Model(nn.Module):
         if eps_f is None:
             eps_f = torch.randn(N, self.samples_f, device=dev)
         return render_test(self, model_coarse, model_fine, rays_d.float(), rays_o.float(),
-                           self._dev(eps_c).contiguous(), self._dev(eps_sel).contiguous(), self._dev(eps_f).contiguous())
+                           self._dev(eps_c).contiguous(), self._dev(eps_sel).contiguous(), self._dev(eps_f).contiguous(), _prepared)
 
     # ------------------------------------------------------------------ per-pass API of the reference (:682-736)
     @torch.no_grad()
@@ -273,8 +273,15 @@ class NeRF_Model(nn.Module):
         rgb = torch.empty(M, 3, dtype=torch.float32, device=rays_d.device)
         depth = torch.empty(M, 1, dtype=torch.float32, device=rays_d.device)
         opac = torch.empty(M, 1, dtype=torch.float32, device=rays_d.device)
+        # the weights are constant inside the loop: re-layout them (and upload the BARF weights) once per image, not per chunk
+        prec = self.settings.precision
+        prepared = None
+        if M > 0:
+            prepared = (ops.pack_weights(model_coarse.net, model_coarse.flat_params(), precision=prec),
+                        ops.pack_weights(model_fine.net, model_fine.flat_params(), precision=prec),
+                        self.emmbedding_xyz.barf_weights_on(1, rays_d.device))
         for i in range(0, M, chunk):
-            r, d, o = self.render_rays_test(rays_d[i:i + chunk], rays_o[i:i + chunk], model_coarse, model_fine)
+            r, d, o = self.render_rays_test(rays_d[i:i + chunk], rays_o[i:i + chunk], model_coarse, model_fine, _prepared=prepared)
             rgb[i:i + chunk], depth[i:i + chunk], opac[i:i + chunk] = r, d, o
         return rgb, depth, opac
 

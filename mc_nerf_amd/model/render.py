@@ -166,18 +166,21 @@ class RenderTrainFn(torch.autograd.Function):
                                d_o if ctx.needs_input_grad[11] else None) + tuple(grads_c) + tuple(grads_f)
 
 
-def render_test(owner, model_c, model_f, rays_d, rays_o, eps_c, eps_sel, eps_f):
-    """NeRF_Model.render_rays_test (model/mc_nerf.py:648-680): no jitter, step_r = 1, no cap, no grad."""
+def render_test(owner, model_c, model_f, rays_d, rays_o, eps_c, eps_sel, eps_f, prepared=None):
+    """NeRF_Model.render_rays_test (model/mc_nerf.py:648-680): no jitter, step_r = 1, no cap, no grad.
+    `prepared` = (packed_c, packed_f, barf_w) from an enclosing chunk loop (the weights do not change inside it)."""
     st: RenderSettings = owner.settings
     dev = rays_d.device
     N = rays_d.shape[0]
     rays_d = rays_d.contiguous()
     rays_o = rays_o.contiguous()
-    barf_w = owner.emmbedding_xyz.barf_weights_on(1, dev)
     net_c, net_f = model_c.net, model_f.net
     flat_c, flat_f = model_c.flat_params(), model_f.flat_params()
     prec = st.precision
-    packed_c, packed_f = ops.pack_weights(net_c, flat_c, precision=prec), ops.pack_weights(net_f, flat_f, precision=prec)
+    if prepared is None:
+        prepared = (ops.pack_weights(net_c, flat_c, precision=prec), ops.pack_weights(net_f, flat_f, precision=prec),
+                    owner.emmbedding_xyz.barf_weights_on(1, dev))
+    packed_c, packed_f, barf_w = prepared
     out_c = torch.empty(N, st.samples_c, 4, dtype=torch.float32, device=dev)
     ops.mlp_fwd(net_c, flat_c, packed_c, rays_o, rays_d, owner.z_vals_c, None, barf_w, out_c, precision=prec)
     _, _, _, w_sel, wmax = ops.composite_fwd(out_c, rays_d, owner.z_vals_c, None, eps_c, eps_sel, st.white_back)
