@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MCNERF_ABI_VERSION 2
+#define MCNERF_ABI_VERSION 3
 
 int mcnerf_abi_version(void);
 const char* mcnerf_last_error(void);
@@ -141,26 +141,30 @@ int mcnerf_mlp_dw_f16x3(int depth, int width, int skip, const int32_t* count, in
                         const float* act_save, const float* enc_save, const float* dy_save, const float* dsh_save,
                         long long capacity, float* grads, const uint32_t* gmax_bits, void* stream);
 
-/* ---- Single-pass 16-bit MFMA mode (dtype 0 = f16, 1 = bf16): one v_mfma_f32_32x32x16_{f16|bf16} per product, fp32
- * accumulate, biases / epilogues / outputs in fp32, 2-byte saved operands (csrc/mcnerf_16.h).  Same reference code
- * replaced as the fp32 entry points above (model/net_block.py:20-35, 67-78; model/net_utils.py:103-191;
- * model/mc_nerf.py:688-701); results agree with the fp32 path to the operand rounding of the dtype (f16: ~1e-3
- * in rgb), NOT to the 1e-4 parity bar - that is what the fp32 / f16x3 modes are for.
- * Packed weights are two 16-bit fragment STREAMS (forward order, backward = transposed order); workspaces are
+/* ---- Register-chain modes (csrc/mcnerf_16.h, csrc/mcnerf_x3.h), selected by `dtype`:
+ *   0 = f16, 1 = bf16: ONE v_mfma_f32_32x32x16_{f16|bf16} per product, fp32 accumulate, biases / epilogues / outputs in
+ *       fp32, 2-byte saved operands.  Results agree with the fp32 path to the operand rounding of the dtype (f16: ~1e-5
+ *       in rgb on the reference's fixtures), NOT in general to the 1e-4 parity bar.
+ *   2 = f16x3: the fp32-GRADE mode.  Every operand is hi + lo (two f16, 22 significand bits), a product is three f16
+ *       MFMAs into one fp32 accumulator (~2^-21 relative product error), saved operands are a hi and a lo plane
+ *       (4 bytes per value).  This is the mode that meets the 1e-4 parity bar at 16-bit MFMA rates.
+ * Same reference code replaced as the fp32 entry points above (model/net_block.py:20-35, 67-78;
+ * model/net_utils.py:103-191; model/mc_nerf.py:688-701).
+ * Packed weights are two fragment STREAMS (forward order, backward = transposed order); workspaces are
  * fragment-major and sized by mcnerf_ws_bytes_16 (capacity is rounded up to whole 256-row passes inside). */
-long long mcnerf_packed_bytes_16(int depth, int width, int skip, int backward);
+long long mcnerf_packed_bytes_16(int depth, int width, int skip, int dtype, int backward);
 int mcnerf_pack_weights_16(int depth, int width, int skip, const float* params, void* packed_fwd, void* packed_bwd,
                            int dtype, void* stream);
 /* which: 0 = activations or pre-activation gradients (all depth+2 slots), 1 = encodings, 2 = ReLU bit masks (all slots),
  *        3 = d(sh.2 outputs / sigma_raw), 4 = sh.2 outputs */
-long long mcnerf_ws_bytes_16(int depth, int width, long long capacity, int which);
-/* mcnerf_mlp_fwd in the 16-bit mode.  act_ws / enc_ws / mask_ws / sh_ws: NULL (all four) for the no-grad path. */
+long long mcnerf_ws_bytes_16(int depth, int width, int dtype, long long capacity, int which);
+/* mcnerf_mlp_fwd in these modes.  act_ws / enc_ws / mask_ws / sh_ws: NULL (all four) for the no-grad path. */
 int mcnerf_mlp_fwd_16(int depth, int width, int skip, int dtype, const float* params, const void* packed_fwd,
                       const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
                       const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                       int n_rays, int S, float* out,
                       void* act_ws, long long capacity, void* enc_ws, uint32_t* mask_ws, void* sh_ws, void* stream);
-/* mcnerf_mlp_bwd in the 16-bit mode: dy_ws / dsh_ws receive 16-bit gradients scaled by the power of two derived from
+/* mcnerf_mlp_bwd in these modes: dy_ws / dsh_ws receive 16-bit (f16x3: hi + lo) gradients scaled by the power of two derived from
  * *gmax_bits (f16 range); d_rays_o / d_rays_d are accumulated in fp32. */
 int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* params, const void* packed_bwd,
                       const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
@@ -168,7 +172,7 @@ int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* pa
                       int n_rays, int S, const float* out, const float* d_out,
                       const uint32_t* mask_ws, long long capacity, const void* enc_ws, const void* sh_ws,
                       void* dy_ws, void* dsh_ws, float* d_rays_o, float* d_rays_d, const uint32_t* gmax_bits, void* stream);
-/* mcnerf_mlp_dw in the 16-bit mode (fp32 accumulation and fp32 float-atomic output into `grads`). */
+/* mcnerf_mlp_dw in these modes (fp32 accumulation and fp32 float-atomic output into `grads`). */
 int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const int32_t* count, int rows,
                      const void* act_ws, const void* enc_ws, const void* dy_ws, const void* dsh_ws,
                      long long capacity, float* grads, const uint32_t* gmax_bits, void* stream);

@@ -3,6 +3,7 @@
 #include "../../include/mcnerf.h"
 #include "mcnerf_kernels.h"
 #include "mcnerf_16.h"
+#include "mcnerf_x3.h"
 #ifdef ABL_ALIAS     // (ablation build only: every workspace slot aliases slot 0 = same bytes moved, 1/10 of the footprint)
 #define MCN_ACT_STRIDE(capacity, width) ((size_t)0)
 #else
@@ -223,24 +224,30 @@ int mcnerf_mlp_dw_f16x3(int depth, int width, int skip, const int32_t* count, in
     return check("mcnerf_mlp_dw_f16x3", mcn_launch_dw(a, (hipStream_t)stream));
 }
 
-// ---- single-pass 16-bit mode (mcnerf_16.h)
-long long mcnerf_packed_bytes_16(int depth, int width, int skip, int backward) {
-    if (!net_ok(depth, width, skip)) return -1;
+// ---- register-chain modes: single-pass 16-bit (mcnerf_16.h; dtype 0 = f16, 1 = bf16) and split-f16 "f16x3" (mcnerf_x3.h; dtype 2)
+static bool dtype_ok(int dtype) { return dtype == 0 || dtype == 1 || dtype == 2; }
+long long mcnerf_packed_bytes_16(int depth, int width, int skip, int dtype, int backward) {
+    if (!net_ok(depth, width, skip) || !dtype_ok(dtype)) return -1;
     const McnLayout L = mcn_make_layout(depth, width, skip);
+    if (dtype == 2) return (long long)(backward ? mcnx3_bwd_stream(L) : mcnx3_fwd_stream(L)).total_frags * 2048;
     return (long long)(backward ? mcn16_bwd_stream(L) : mcn16_fwd_stream(L)).total_frags * 1024;
 }
 int mcnerf_pack_weights_16(int depth, int width, int skip, const float* params, void* packed_fwd, void* packed_bwd,
                            int dtype, void* stream) {
-    REQ(net_ok(depth, width, skip) && params && packed_fwd && packed_bwd && (dtype == 0 || dtype == 1), "mcnerf_pack_weights_16");
+    REQ(net_ok(depth, width, skip) && params && packed_fwd && packed_bwd && dtype_ok(dtype), "mcnerf_pack_weights_16");
+    if (dtype == 2) return check("mcnerf_pack_weights_16", mcnx3_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, (hipStream_t)stream));
     return check("mcnerf_pack_weights_16", mcn16_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, dtype, (hipStream_t)stream));
 }
-long long mcnerf_ws_bytes_16(int depth, int width, long long capacity, int which) {
-    if (!net_ok(depth, width, 0) || capacity < 0) return -1;
+static size_t slot_bytes_of(int dtype, long long capacity, int width) { return dtype == 2 ? mcnx3_slot_bytes(capacity, width) : mcn16_slot_bytes(capacity, width); }
+long long mcnerf_ws_bytes_16(int depth, int width, int dtype, long long capacity, int which) {
+    if (!net_ok(depth, width, 0) || capacity < 0 || !dtype_ok(dtype)) return -1;
+    const bool x3 = dtype == 2;
     switch (which) {
-        case 0: return (long long)(depth + 2) * (long long)mcn16_slot_bytes(capacity, width);
-        case 1: return (long long)mcn16_enc_bytes(capacity);
+        case 0: return (long long)(depth + 2) * (long long)slot_bytes_of(dtype, capacity, width);
+        case 1: return (long long)(x3 ? mcnx3_enc_bytes(capacity) : mcn16_enc_bytes(capacity));
         case 2: return (long long)(depth + 2) * (long long)mcn16_mask_slot_bytes(capacity, width);
-        case 3: case 4: return (long long)mcn16_dsh_bytes(capacity);
+        case 3: return (long long)(x3 ? mcnx3_dsh_bytes(capacity) : mcn16_dsh_bytes(capacity));
+        case 4: return (long long)(x3 ? mcnx3_sh_bytes(capacity) : mcn16_dsh_bytes(capacity));
     }
     return -1;
 }
@@ -249,7 +256,7 @@ int mcnerf_mlp_fwd_16(int depth, int width, int skip, int dtype, const float* pa
                       const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                       int n_rays, int S, float* out,
                       void* act_ws, long long capacity, void* enc_ws, uint32_t* mask_ws, void* sh_ws, void* stream) {
-    REQ(net_ok(depth, width, skip) && (dtype == 0 || dtype == 1), "mcnerf_mlp_fwd_16");
+    REQ(net_ok(depth, width, skip) && dtype_ok(dtype), "mcnerf_mlp_fwd_16");
     REQ(params && packed_fwd && rays_o && rays_d && zgrid && barf_w && out && n_rays >= 0 && S > 0, "mcnerf_mlp_fwd_16");
     REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_fwd_16");
     REQ(!idx || max_rows >= 0, "mcnerf_mlp_fwd_16");
@@ -258,12 +265,13 @@ int mcnerf_mlp_fwd_16(int depth, int width, int skip, int dtype, const float* pa
     if (act_ws) REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_fwd_16");
     Mcn16FwdArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
-    a.params = params; a.packed = packed_fwd; a.stream_slabs = mcn16_fwd_stream(a.lay).total_frags / MCN16_SLAB; a.bf16 = dtype;
+    a.params = params; a.packed = packed_fwd; a.bf16 = dtype;
+    a.stream_slabs = dtype == 2 ? mcnx3_fwd_stream(a.lay).total_frags / MCNX3_SLABF : mcn16_fwd_stream(a.lay).total_frags / MCN16_SLAB;
     a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter; a.barf_w = barf_w;
     a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S; a.out = out;
-    a.act_ws = act_ws; a.slot_bytes = mcn16_slot_bytes(capacity, width); a.enc_ws = enc_ws;
+    a.act_ws = act_ws; a.slot_bytes = slot_bytes_of(dtype, capacity, width); a.enc_ws = enc_ws;
     a.mask_ws = mask_ws; a.mask_slot_words = mcn16_mask_slot_bytes(capacity, width) / 4; a.sh_ws = sh_ws;
-    return check("mcnerf_mlp_fwd_16", mcn16_launch_fwd(a, (hipStream_t)stream));
+    return check("mcnerf_mlp_fwd_16", dtype == 2 ? mcnx3_launch_fwd(a, (hipStream_t)stream) : mcn16_launch_fwd(a, (hipStream_t)stream));
 }
 int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* params, const void* packed_bwd,
                       const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
@@ -271,31 +279,32 @@ int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* pa
                       int n_rays, int S, const float* out, const float* d_out,
                       const uint32_t* mask_ws, long long capacity, const void* enc_ws, const void* sh_ws,
                       void* dy_ws, void* dsh_ws, float* d_rays_o, float* d_rays_d, const uint32_t* gmax_bits, void* stream) {
-    REQ(net_ok(depth, width, skip) && (dtype == 0 || dtype == 1), "mcnerf_mlp_bwd_16");
+    REQ(net_ok(depth, width, skip) && dtype_ok(dtype), "mcnerf_mlp_bwd_16");
     REQ(params && packed_bwd && gmax_bits && rays_o && rays_d && zgrid && barf_w && out && d_out && n_rays >= 0 && S > 0, "mcnerf_mlp_bwd_16");
     REQ(mask_ws && enc_ws && sh_ws && dy_ws && dsh_ws, "mcnerf_mlp_bwd_16");
     REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_bwd_16");
     REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_bwd_16");
     Mcn16BwdArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
-    a.params = params; a.packed = packed_bwd; a.stream_slabs = mcn16_bwd_stream(a.lay).total_frags / MCN16_SLAB; a.bf16 = dtype;
+    a.params = params; a.packed = packed_bwd; a.bf16 = dtype;
+    a.stream_slabs = dtype == 2 ? mcnx3_bwd_stream(a.lay).total_frags / MCNX3_SLABF : mcn16_bwd_stream(a.lay).total_frags / MCN16_SLAB;
     a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter; a.barf_w = barf_w;
     a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
     a.out = out; a.d_out = d_out; a.mask_ws = mask_ws; a.mask_slot_words = mcn16_mask_slot_bytes(capacity, width) / 4;
-    a.enc_ws = enc_ws; a.sh_ws = sh_ws; a.dy_ws = dy_ws; a.slot_bytes = mcn16_slot_bytes(capacity, width); a.dsh_ws = dsh_ws;
+    a.enc_ws = enc_ws; a.sh_ws = sh_ws; a.dy_ws = dy_ws; a.slot_bytes = slot_bytes_of(dtype, capacity, width); a.dsh_ws = dsh_ws;
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d; a.gmax_bits = gmax_bits;
-    return check("mcnerf_mlp_bwd_16", mcn16_launch_bwd(a, (hipStream_t)stream));
+    return check("mcnerf_mlp_bwd_16", dtype == 2 ? mcnx3_launch_bwd(a, (hipStream_t)stream) : mcn16_launch_bwd(a, (hipStream_t)stream));
 }
 int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const int32_t* count, int rows,
                      const void* act_ws, const void* enc_ws, const void* dy_ws, const void* dsh_ws,
                      long long capacity, float* grads, const uint32_t* gmax_bits, void* stream) {
-    REQ(net_ok(depth, width, skip) && (dtype == 0 || dtype == 1), "mcnerf_mlp_dw_16");
+    REQ(net_ok(depth, width, skip) && dtype_ok(dtype), "mcnerf_mlp_dw_16");
     REQ(act_ws && enc_ws && dy_ws && dsh_ws && grads && gmax_bits && rows >= 0 && capacity >= rows, "mcnerf_mlp_dw_16");
     Mcn16DwArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
     a.bf16 = dtype; a.count = count; a.rows = rows; a.act_ws = act_ws; a.enc_ws = enc_ws; a.dy_ws = dy_ws; a.dsh_ws = dsh_ws;
-    a.slot_bytes = mcn16_slot_bytes(capacity, width); a.grads = grads; a.gmax_bits = gmax_bits;
-    return check("mcnerf_mlp_dw_16", mcn16_launch_dw(a, (hipStream_t)stream));
+    a.slot_bytes = slot_bytes_of(dtype, capacity, width); a.grads = grads; a.gmax_bits = gmax_bits;
+    return check("mcnerf_mlp_dw_16", dtype == 2 ? mcnx3_launch_dw(a, (hipStream_t)stream) : mcn16_launch_dw(a, (hipStream_t)stream));
 }
 
 int mcnerf_composite_fwd(const float* sig_rgb, const float* rays_d, const float* zgrid, const float* jitter,

@@ -1,0 +1,143 @@
+// Split-f16 ("f16x3") mode of the NeRF MLP kernels on the register-chain / shared-ring / fragment-major architecture of
+// mcnerf_16.h: the fp32-grade mode (every fp32 operand x = (hi + lo) / scale with hi = f16(x * scale), lo = f16(x * scale - hi):
+// 22 significand bits; a product is hi*hi + hi*lo + lo*hi = three v_mfma_f32_32x32x16_f16 into one fp32 accumulator,
+// relative product error ~2^-21 against fp32's 2^-24).  Everything mcnerf_16.h says about the orientation, the
+// contraction-index permutation c(s,h,j) and the fragment-major workspaces holds here, with one difference per item:
+//
+//  * REGISTER-CHAINED LAYERS.  A wave still carries 32 samples through the network in registers, but a layer's input and
+//    output are now TWO fragments per k-step (hi, lo): 128 + 128 registers at width 256.  The 256-wide net therefore
+//    runs ONE wave per SIMD (4 waves = 128 samples per workgroup pass, 512 registers per lane); narrower nets keep 8 waves.
+//  * SHARED WEIGHT STREAM.  The packed stream holds, per logical fragment, the hi piece (1 KiB) followed by the lo piece;
+//    a ring slab is 8 logical fragments (16 pieces = 16 KiB, the same slab size and ring as the 16-bit mode), every wave
+//    issues 16 / WAVES pieces per slab.  One slab = 24 MFMAs per wave.
+//  * FRAGMENT-MAJOR WORKSPACES.  ws[slot][tile of 32 rows][part hi / lo][k-step][lane][8 x f16]: the two planes of a tile
+//    are adjacent (2 * KS KiB per tile); the ReLU bit masks are those of the 16-bit mode (bit = hi half non-zero).
+//
+// Scales (powers of two, so they commute with every rounding): weights SW = 2^8 (lo stays a normal f16 down to
+// |w| ~ 5e-4), activations SX = 2^3 (|x| <= 8188), gradients SG = the per-launch power of two of the 16-bit mode.
+#pragma once
+#include "mcnerf_16.h"
+
+#define MCNX3_SW 256.0f
+#define MCNX3_SX 8.0f
+#define MCNX3_SLABF 8                  // logical fragments (hi + lo piece) per ring slab
+#ifndef MCNX3_PF
+#define MCNX3_PF 2                     // A fragments (pairs) read this many k-steps ahead of their MFMAs
+#endif
+
+// waves per workgroup by net width (the wave count decides rows per pass and ring pieces per wave)
+static inline constexpr int mcnx3_waves(int width) { return width >= 256 ? 4 : 8; }
+
+static inline int mcnx3_pad(int frags) { return (frags + MCNX3_SLABF - 1) / MCNX3_SLABF * MCNX3_SLABF; }
+// The 16-bit streams with the segments padded to whole x3 slabs (first_frag / total_frags count LOGICAL fragments of 2 KiB).
+static inline Mcn16Stream mcnx3_repad(Mcn16Stream st) {
+    int total = 0;
+    for (int s = 0; s < st.nseg; ++s) {
+        st.seg[s].first_frag = total;
+        total += mcnx3_pad(st.seg[s].tiles * (st.seg[s].a.ksteps + st.seg[s].b.ksteps));
+    }
+    st.total_frags = total;
+    return st;
+}
+static inline Mcn16Stream mcnx3_fwd_stream(const McnLayout& L) { return mcnx3_repad(mcn16_fwd_stream(L)); }
+static inline Mcn16Stream mcnx3_bwd_stream(const McnLayout& L) { return mcnx3_repad(mcn16_bwd_stream(L)); }
+
+// Workspace geometry (bytes): twice the 16-bit planes; the sh.2 outputs are kept as the fp32 accumulator tile (4 KiB per tile).
+static inline size_t mcnx3_slot_bytes(long long capacity, int width) { return 2 * mcn16_slot_bytes(capacity, width); }
+static inline size_t mcnx3_enc_bytes(long long capacity) { return 2 * mcn16_enc_bytes(capacity); }
+static inline size_t mcnx3_sh_bytes(long long capacity) { return (size_t)mcn16_cap_tiles(capacity) * 4096; }
+static inline size_t mcnx3_dsh_bytes(long long capacity) { return 2 * mcn16_dsh_bytes(capacity); }
+
+hipError_t mcnx3_launch_fwd(const Mcn16FwdArgs& a, hipStream_t st);
+hipError_t mcnx3_launch_bwd(const Mcn16BwdArgs& a, hipStream_t st);
+hipError_t mcnx3_launch_dw(const Mcn16DwArgs& a, hipStream_t st);
+hipError_t mcnx3_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, hipStream_t st);
+
+#ifdef __HIPCC__
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// (a, b) * 1 -> packed hi halves and packed lo halves (a in the low 16 bits)
+__device__ __forceinline__ void mcnx3_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const f16x2_t h = __builtin_convertvector((f32x2_t){a, b}, f16x2_t);
+    const f32x2_t back = __builtin_convertvector(h, f32x2_t);
+    const f16x2_t l = __builtin_convertvector((f32x2_t){a - back[0], b - back[1]}, f16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// value of element e (0 / 1) of a (hi, lo) word pair
+__device__ __forceinline__ float mcnx3_val(unsigned hi, unsigned lo, int e) {
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, hi), l = __builtin_bit_cast(f16x2_t, lo);
+    return (float)h[e] + (float)l[e];
+}
+__device__ __forceinline__ float mcnx3_relu(float x) {       // integer max: no canonicalising v_max in front
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+__device__ __forceinline__ f32x16 mcnx3_mfma(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// acc += (ah + al) (bh + bl) without the lo * lo term; smallest terms first
+__device__ __forceinline__ void mcnx3_mfma3(f32x16& acc, const u32x4_t& ah, const u32x4_t& al, const u32x4_t& bh, const u32x4_t& bl) {
+    acc = mcnx3_mfma(al, bh, acc);
+    acc = mcnx3_mfma(ah, bl, acc);
+    acc = mcnx3_mfma(ah, bh, acc);
+}
+
+// ---- the shared weight ring with PPW pieces per wave and slab (Mcn16Ring state, mcnerf_16.h)
+template <int PPW>
+__device__ __forceinline__ void mcnx3_ring_issue(Mcn16Ring& r) {
+    const char* s = r.src + (size_t)r.src_slab * (MCN16_SLAB * 1024);
+    const unsigned d = r.lds_base + r.issue_slot * (MCN16_SLAB * 1024) + r.lds_piece;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) mcn16_dma16(s + i * 1024, d + i * 1024);
+    r.src_slab = (r.src_slab + 1 == r.n_slabs) ? 0 : r.src_slab + 1;
+    r.issue_slot = (r.issue_slot + 1) & (MCN16_RING - 1);
+}
+template <int PPW>
+__device__ __forceinline__ void mcnx3_ring_sync(Mcn16Ring& r) {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW * (MCN16_AHEAD - 1)) : "memory");
+    r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
+    r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
+    mcnx3_ring_issue<PPW>(r);
+}
+template <int PPW>
+__device__ __forceinline__ void mcnx3_ring_start(Mcn16Ring& r, char* ring_lds, const void* packed, int n_slabs, int wave, int lane) {
+    r.src = reinterpret_cast<const char*>(packed) + (PPW * wave) * 1024 + lane * 16;
+    r.lds_piece = (PPW * wave) * 1024;
+    r.lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)ring_lds);
+    r.src_slab = 0; r.n_slabs = n_slabs; r.issue_slot = 0; r.sync_slot = 0; r.next_off = 0;
+#pragma unroll
+    for (int i = 0; i < MCN16_AHEAD; ++i) mcnx3_ring_issue<PPW>(r);
+    mcnx3_ring_sync<PPW>(r);
+}
+// Fragment f of a layer of F logical fragments: the slab after the one being consumed is synchronised PF fragments before
+// the current one ends, so the A prefetch runs across slab boundaries (as mcn16_before_mfma).
+template <int F, int PPW>
+__device__ __forceinline__ void mcnx3_before_mfma(Mcn16Ring& r, Mcn16Cursor& c, int f) {
+    if ((f & (MCNX3_SLABF - 1)) == 0) c.cur = r.next_off;
+    const int q = f / MCNX3_SLABF;
+    const int sync_at = (MCNX3_SLABF * q + MCNX3_SLABF - MCNX3_PF) < (F - 1) ? (MCNX3_SLABF * q + MCNX3_SLABF - MCNX3_PF) : (F - 1);
+    if (f == sync_at) mcnx3_ring_sync<PPW>(r);
+}
+// LDS byte offset of the hi piece of fragment f (lo piece: + 1024)
+__device__ __forceinline__ unsigned mcnx3_frag_off(const Mcn16Ring& r, const Mcn16Cursor& c, int f_now, int f) {
+    const bool next = (f / MCNX3_SLABF) != (f_now / MCNX3_SLABF);
+    return (next ? r.next_off : c.cur) + (f & (MCNX3_SLABF - 1)) * 2048;
+}
+
+// The 63 (+1 pad) encoded channels of one sample, fp32-accurate: sin / cos of 2^f x by an fp64 range reduction per
+// octave (mcn_sincos), times the BARF weight of f (model/net_block.py:22-33 order: x, y, z, then per axis sin f = 0..9, cos f = 0..9).
+__device__ __forceinline__ void mcnx3_encode_values(const float (&p)[3], const float (&bw)[MCN_NFREQ], float (&E)[64]) {
+    E[0] = p[0]; E[1] = p[1]; E[2] = p[2]; E[63] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int f = 0; f < MCN_NFREQ; ++f) {
+            float s, c;
+            mcn_sincos(p[a] * (float)(1 << f), s, c);          // exact: power-of-two scale
+            E[3 + 20 * a + f] = s * bw[f];
+            E[3 + 20 * a + 10 + f] = c * bw[f];
+        }
+    }
+}
+#endif

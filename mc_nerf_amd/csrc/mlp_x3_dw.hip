@@ -1,0 +1,302 @@
+// Weight / bias gradients of the NeRF MLPs, split-f16 ("f16x3") mode (mcnerf_x3.h):
+//     dW[n][k] = sum_m dY[m][n] X[m][k],   db[n] = sum_m dY[m][n]
+// over the fragment-major (hi plane, lo plane) workspaces written by mlp_x3_fwd.hip (X, scaled by SX) and mlp_x3_bwd.hip
+// (dY, scaled by SG): dY_hi X_hi + dY_hi X_lo + dY_lo X_hi, three MFMAs per product into one fp32 accumulator.
+// Replaces the dW half of autograd's addmm backward for every nn.Linear of CorseFine_NeRF (model/net_block.py:51-65).
+//
+// Same streaming structure as mlp16_dw.hip (one launch per net; the segments' 32-row tiles form one linear sequence cut
+// into gridDim.x pieces; persistent 8-wave workgroup per CU; LDS ring of whole tiles filled by LDS-DMA with the
+// non-temporal policy; both operands read with ds_read_b64_tr_b16; a block flushed with fp32 atomics when a workgroup's
+// piece leaves a segment).  A tile is now 2 (N + K) / 16 pieces of 1 KiB (the hi pieces of dY and X, then the lo pieces),
+// so the ring holds as many stages as fit 160 KiB (2 for the 256 x 256 blocks).
+#include "mcnerf_x3.h"
+
+struct DwX3Seg {
+    const char* dY; int ksn;      // fragment-major [tile][part][ksn][64][8]: N = 16 ksn columns
+    const char* X;  int ksk;      // fragment-major [tile][part][ksk][64][8]: K = 16 ksk columns
+    const char* X2; int ksk2;     // optional second input block (the skip layer: [hidden | encoded] in ONE pass); null / 0 otherwise
+    int n_lo, n_real;             // outputs n_lo <= n < n_real are real (row n - n_lo of dW)
+    int col, k_real;              // input k < K of X is real for k < k_real and lands in column col + k of the dW row
+    int col2, k_real2;            // input K + k of X2: column col2 + k, real for k < k_real2
+    float* dW; int ldw;
+    float* db;
+};
+
+constexpr int dwx3_pick(int N, int K, bool want_vn) {
+    int bestG = 0, bestVN = 1, bestKT = 1;
+    for (int vn = 4; vn >= 1; vn /= 2)
+        for (int kt = 5; kt >= 1; --kt) {
+            if (32 * vn > N || 32 * kt > K || K % (32 * kt) != 0) continue;
+            const int g = (N / (32 * vn)) * (K / (32 * kt));
+            if (g > MCN16_WAVES) continue;
+            const bool better = g > bestG || (g == bestG && vn * kt > bestVN * bestKT) || (g == bestG && vn * kt == bestVN * bestKT && vn > bestVN);
+            if (better) { bestG = g; bestVN = vn; bestKT = kt; }
+        }
+    return want_vn ? bestVN : bestKT;
+}
+constexpr int dwx3_stages(int pieces) {            // ring stages of `pieces` KiB that fit the CU's LDS (at most 4)
+    const int s = 160 / pieces;
+    return s > 4 ? 4 : (s < 2 ? 2 : s);
+}
+
+// tiles [t0, t1) of one segment: stream, accumulate, flush.
+template <int N, int K1, int K2>
+__device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const int t1, const float sgs, char* smem) {
+    constexpr int K = K1 + K2;
+    constexpr int KSN = N / 16, KSK1 = K1 / 16, KSK2 = K2 / 16, P = KSN + KSK1 + KSK2, P2 = 2 * P;   // 1 KiB pieces per tile
+    constexpr int PW = (P2 + MCN16_WAVES - 1) / MCN16_WAVES;
+    constexpr int VN = dwx3_pick(N, K, true), KT = dwx3_pick(N, K, false);
+    constexpr int NG = N / (32 * VN), KG = K / (32 * KT), G = NG * KG, MS = MCN16_WAVES / G;
+    static_assert(G >= 1 && MCN16_WAVES % G == 0, "wave tiling");
+    constexpr int STAGE = P2 * 1024, ST = dwx3_stages(P2), AH = ST - 1;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gi = wave % G, ms = wave / G;
+    const int nbase = (gi % NG) * 32 * VN, kbase = (gi / NG) * 32 * KT;
+
+    // ---- LDS-DMA pieces of this wave: piece pi = wave + 8 i; pieces 0 .. P-1 = hi (dY, X, X2 fragments), P .. 2P-1 = lo
+    const unsigned lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem);
+    const char* src[PW];
+    int step[PW];
+    const int hh = lane >> 5, mm = lane & 31;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int pi = wave + MCN16_WAVES * i;
+        const int part = pi >= P ? 1 : 0, q = pi - part * P;
+        const int which = q < KSN ? 0 : (q < KSN + KSK1 ? 1 : 2);
+        const int s = which == 0 ? q : (which == 1 ? q - KSN : q - KSN - KSK1);
+        const int ks = which == 0 ? KSN : (which == 1 ? KSK1 : KSK2);
+        const int m_src = mm ^ (4 * (2 * (s & 1) + hh));
+        const char* base = which == 0 ? sg.dY : (which == 1 ? sg.X : sg.X2);
+        src[i] = (pi < P2 && base) ? base + ((size_t)t0 * 2 * ks + part * ks + s) * 1024 + (hh * 32 + m_src) * 16 : nullptr;
+        step[i] = 2 * ks * 1024;
+    }
+    const int np = (P2 % MCN16_WAVES == 0 || wave < P2 % MCN16_WAVES) ? PW : PW - 1;      // wave-uniform
+    auto fill = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int pi = wave + MCN16_WAVES * i;
+            if (i < np) mcn16_dma16_nt(src[i], lds_base + stage * STAGE + pi * 1024);
+            src[i] += step[i];
+        }
+    };
+#define DWX3_WAIT_ASM(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
+#define DWX3_WAIT(k) do { if (np == PW) DWX3_WAIT_ASM((k) * PW); else DWX3_WAIT_ASM((k) * (PW - 1)); } while (0)
+
+    f32x16 acc[VN][KT];
+    mcn_zero<VN, KT>(acc);
+    float bsum[VN];
+#pragma unroll
+    for (int t = 0; t < VN; ++t) bsum[t] = 0.f;
+    const bool bias = sg.db && kbase == 0;                            // wave-uniform
+
+    // ---- per-lane LDS offsets of the transposed reads (mlp16_dw.hip)
+    const int g16 = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int hp = p & 1;
+    const int cxor = 4 * (2 * (g16 & 1) + hp);
+    int roff[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int m = 16 * u + 8 * (g16 >> 1) + 4 * v + q;
+            roff[u][v] = (hp * 32 + (m ^ cxor)) * 16 + 8 * (p >> 1);
+        }
+    const int fragA0 = (nbase / 16) + (g16 & 1);
+    const int fragB0 = KSN + (kbase / 16) + (g16 & 1);
+
+    int nt = t1 - t0;
+#pragma unroll
+    for (int i = 0; i < AH; ++i)
+        if (i < nt) fill(i);
+    {
+        const int younger = min(nt, AH) - 1;
+        if (younger >= 2) DWX3_WAIT(2); else if (younger == 1) DWX3_WAIT(1); else DWX3_WAIT(0);
+    }
+    static_assert(AH <= 3, "wait ladder covers up to 2 younger tiles");
+    int cur = 0;
+    auto frag = [&](const char* fp, int u) -> u32x4_t {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(fp + roff[u][0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(fp + roff[u][1]));
+        const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+        return u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+    };
+    for (int it = 0; it < nt; ++it) {
+        if (it + AH < nt) fill((cur + AH) % ST);
+        if ((it % MS) == ms) {                                        // wave-uniform: waves sharing an output tile alternate tiles
+            const char* st = smem + cur * STAGE;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                u32x4_t ah[VN], al[VN], bh[KT], bl[KT];
+#pragma unroll
+                for (int t = 0; t < VN; ++t) {
+                    ah[t] = frag(st + (fragA0 + 2 * t) * 1024, u);
+                    al[t] = frag(st + (P + fragA0 + 2 * t) * 1024, u);
+                }
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    bh[t] = frag(st + (fragB0 + 2 * t) * 1024, u);
+                    bl[t] = frag(st + (P + fragB0 + 2 * t) * 1024, u);
+                }
+#pragma unroll
+                for (int t = 0; t < VN; ++t) {
+                    if (bias) {          // column sums of dY: the 8 samples of this lane's column, hi + lo
+                        const f16x2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+                        const f16x8_t hv = __builtin_bit_cast(f16x8_t, ah[t]), lv = __builtin_bit_cast(f16x8_t, al[t]);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            bsum[t] = __builtin_amdgcn_fdot2(f16x2_t{hv[2 * d], hv[2 * d + 1]}, ones, bsum[t], false);
+                            bsum[t] = __builtin_amdgcn_fdot2(f16x2_t{lv[2 * d], lv[2 * d + 1]}, ones, bsum[t], false);
+                        }
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) mcnx3_mfma3(acc[t][kt], ah[t], al[t], bh[kt], bl[kt]);
+                }
+            }
+        }
+        const int left = nt - 1 - it;
+        const int younger = min(left, AH) - 1;
+        if (younger >= 2) DWX3_WAIT(2); else if (younger == 1) DWX3_WAIT(1); else DWX3_WAIT(0);
+        cur = (cur + 1) % ST;
+    }
+#undef DWX3_WAIT
+#undef DWX3_WAIT_ASM
+    // ---- accumulators -> global (float atomics; one register = two 128-byte row segments)
+    const int r = lane & 31, h = lane >> 5;
+    const float inv = 1.0f / (sgs * MCNX3_SX), inv_b = 1.0f / sgs;
+#pragma unroll
+    for (int t = 0; t < VN; ++t)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int k = kbase + 32 * kt + r;
+            const bool in2 = K2 > 0 && kbase + 32 * kt >= K1;
+            const bool k_ok = in2 ? (k - K1 < sg.k_real2) : (k < sg.k_real);
+            const int colk = in2 ? sg.col2 + (k - K1) : sg.col + k;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n >= sg.n_lo && n < sg.n_real && k_ok) atomicAdd(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + colk, acc[t][kt][e] * inv);
+            }
+        }
+    if (bias) {
+#pragma unroll
+        for (int t = 0; t < VN; ++t) {
+            const float b = (bsum[t] + __shfl_xor(bsum[t], 32)) * inv_b;
+            const int n = nbase + 32 * t + r;
+            if (h == 0 && n >= sg.n_lo && n < sg.n_real) atomicAdd(sg.db + (n - sg.n_lo), b);
+        }
+    }
+}
+
+// ---- one launch per net ---------------------------------------------------------------------------------------------
+#define DWX3_MAXSEG 15
+struct DwX3Job {
+    int n;
+    int shape[DWX3_MAXSEG];       // 0: W x W   1: W x 64 (encoded-input columns)   2: 32 x W (sh.2 / sigma.2 rows)   3: W x (W + 64) (skip layer)
+    DwX3Seg seg[DWX3_MAXSEG];
+};
+template <int W> struct DwX3SkipMerged { static constexpr bool value = (W == 256) || (W == 128); };
+
+template <int W>
+__global__ __launch_bounds__(64 * MCN16_WAVES) void dwx3_stream_kernel(DwX3Job job, const int* count, int rows_cap, const unsigned* gmax_bits) {
+    constexpr bool SKIP_MERGED = DwX3SkipMerged<W>::value;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rows = count ? min(*count, rows_cap) : rows_cap;
+    const int ntiles = (rows + 31) / 32;
+    if (ntiles <= 0) return;
+    const float gmax = gmax_bits ? __uint_as_float(*gmax_bits) : 1.f;
+    const float sgs = (gmax > 0.f && gmax < 3e38f) ? exp2f(4.f - ceilf(log2f(gmax))) : 1.f;
+    auto pieces = [](int shape) { return shape == 0 ? 2 * W / 16 : shape == 1 ? W / 16 + MCN16_ENCKS : shape == 2 ? 2 + W / 16 : 2 * W / 16 + MCN16_ENCKS; };
+    long long total = 0;
+    for (int s = 0; s < job.n; ++s) total += (long long)pieces(job.shape[s]) * ntiles;
+    const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
+    long long base = 0;
+    for (int s = 0; s < job.n; ++s) {
+        const int shape = job.shape[s], P = pieces(shape);
+        const long long a = (lo - base + P - 1) / P, e = (hi - base + P - 1) / P;
+        const int t0 = (int)(a < 0 ? 0 : a > ntiles ? ntiles : a), t1 = (int)(e < 0 ? 0 : e > ntiles ? ntiles : e);
+        base += (long long)P * ntiles;
+        if (t0 >= t1) continue;                                        // (block-uniform)
+        if (shape == 0) dwx3_run<W, W, 0>(job.seg[s], t0, t1, sgs, smem);
+        else if (shape == 1) dwx3_run<W, 16 * MCN16_ENCKS, 0>(job.seg[s], t0, t1, sgs, smem);
+        else if (shape == 2) dwx3_run<32, W, 0>(job.seg[s], t0, t1, sgs, smem);
+        else if constexpr (SKIP_MERGED) dwx3_run<W, W, 16 * MCN16_ENCKS>(job.seg[s], t0, t1, sgs, smem);
+    }
+}
+
+static int dwx3_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <int W>
+static hipError_t dwx3_launch_job(const DwX3Job& job, const int* count, int rows_cap, const unsigned* gmax_bits, hipStream_t st) {
+    if (rows_cap <= 0) return hipSuccess;
+    const long long ntiles = (rows_cap + 31) / 32;
+    long long grid = dwx3_num_cus();
+    if (grid > ntiles * job.n) grid = ntiles * job.n;
+    // LDS: the largest stages x stage product over the shapes of this width
+    constexpr int KS = W / 16;
+    constexpr int p0 = 2 * (2 * KS), p1 = 2 * (KS + MCN16_ENCKS), p2 = 2 * (2 + KS), p3 = 2 * (2 * KS + MCN16_ENCKS);
+    constexpr int l0 = dwx3_stages(p0) * p0, l1 = dwx3_stages(p1) * p1, l2 = dwx3_stages(p2) * p2, l3 = DwX3SkipMerged<W>::value ? dwx3_stages(p3) * p3 : 0;
+    constexpr int lmax = (l0 > l1 ? l0 : l1) > (l2 > l3 ? l2 : l3) ? (l0 > l1 ? l0 : l1) : (l2 > l3 ? l2 : l3);
+    static_assert(lmax <= 160, "ring exceeds the CU's LDS");
+    const size_t lds = (size_t)lmax * 1024;
+    void (*kern)(DwX3Job, const int*, int, const unsigned*) = dwx3_stream_kernel<W>;
+    static bool attr_set = false;                                      // (per width instantiation)
+    if (lds > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MCN16_WAVES), lds, st, job, count, rows_cap, gmax_bits);
+    return hipGetLastError();
+}
+
+hipError_t mcnx3_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
+    const McnLayout& L = a.lay;
+    const int W = L.width, D = L.depth, KS = W / 16;
+    auto act = [&](int slot) { return reinterpret_cast<const char*>(a.act_ws) + (size_t)slot * a.slot_bytes; };
+    auto dy = [&](int slot) { return reinterpret_cast<const char*>(a.dy_ws) + (size_t)slot * a.slot_bytes; };
+    const char* enc = reinterpret_cast<const char*>(a.enc_ws);
+    const char* dsh = reinterpret_cast<const char*>(a.dsh_ws);
+    DwX3Job job;
+    job.n = 0;
+    auto add = [&](int shape, const DwX3Seg& s) { job.shape[job.n] = shape; job.seg[job.n] = s; ++job.n; };
+    if (D + 5 > DWX3_MAXSEG) return hipErrorInvalidValue;
+    const bool merged = (W == 256 || W == 128);       // (DwX3SkipMerged)
+    for (int l = 0; l < D; ++l) {
+        const int ldw = mcn_in_features(D, W, L.skip, l);
+        float* dWl = a.grads + L.pW[l];
+        float* dbl = a.grads + L.pB[l];
+        if (l == 0)                       // encoded-input columns only
+            add(1, DwX3Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl});
+        else if (l == L.skip && merged)   // [hidden | encoded] in one pass: hidden k -> column 63 + k, encoded k -> column k
+            add(3, DwX3Seg{dy(l), KS, act(l - 1), KS, enc, MCN16_ENCKS, 0, W, MCN_ENC, W, 0, MCN_ENC, dWl, ldw, dbl});
+        else if (l == L.skip) {
+            add(1, DwX3Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl});
+            add(0, DwX3Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, MCN_ENC, W, 0, 0, dWl, ldw, nullptr});
+        } else
+            add(0, DwX3Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, dWl, ldw, dbl});
+    }
+    add(0, DwX3Seg{dy(D), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWs1, W, a.grads + L.pBs1});
+    add(0, DwX3Seg{dy(D + 1), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWc1, W, a.grads + L.pBc1});
+    add(2, DwX3Seg{dsh, 2, act(D + 1), KS, nullptr, 0, 0, MCN_NSH, 0, W, 0, 0, a.grads + L.pWc2, W, a.grads + L.pBc2});
+    // sigma.2 (1 x W): d sigma sits in column 27 of dsh, its input is the sigma hidden layer
+    add(2, DwX3Seg{dsh, 2, act(D), KS, nullptr, 0, MCN_NSH, MCN_NSH + 1, 0, W, 0, 0, a.grads + L.pWs2, W, a.grads + L.pBs2});
+    switch (W) {
+        case 256: return dwx3_launch_job<256>(job, a.count, a.rows, a.gmax_bits, st);
+        case 128: return dwx3_launch_job<128>(job, a.count, a.rows, a.gmax_bits, st);
+        case 64:  return dwx3_launch_job<64>(job, a.count, a.rows, a.gmax_bits, st);
+        case 32:  return dwx3_launch_job<32>(job, a.count, a.rows, a.gmax_bits, st);
+        default:  return hipErrorInvalidValue;
+    }
+}

@@ -1,0 +1,313 @@
+// Fused NeRF MLP forward, split-f16 ("f16x3") mode on the register-chain architecture (mcnerf_x3.h): sample generation
+// -> sinusoidal encoding -> trunk (+skip) -> sigma / SH heads -> SH colour -> sigmoid.  One wave = 32 samples carried
+// through the whole network in registers as (hi, lo) f16 fragment pairs, three MFMAs per k-step into one fp32
+// accumulator; the waves of a workgroup share the LDS ring that streams the packed (hi, lo) weight pieces.
+// Persistent: one workgroup per CU walks the passes.
+// Replaces (fp32-grade arithmetic: 22-bit operands, fp32 accumulate / bias / ReLU / epilogues) SinCosEmbedding.forward
+// (model/net_block.py:20-35), CorseFine_NeRF.forward (model/net_block.py:67-78), eval_sh (model/net_utils.py:103-191)
+// and the gather / scatter of NeRF_Model.inference (model/mc_nerf.py:688-701).
+#include "mcnerf_x3.h"
+
+template <int W>
+struct FwdX3Smem {
+    static constexpr int oBias = MCN16_RING * MCN16_SLAB * 1024;   // fp32 [MAXD + 2][W]: trunk, sigma.0, sh.0 biases x (SX SW)
+    static constexpr int oW2 = oBias + (MCN_MAXD + 2) * W * 4;     // sigma.2 weight row [W]
+    static constexpr int oBc2 = oW2 + W * 4;                        // sh.2 bias [32] (27 + zero pad) x (SX SW)
+    static constexpr int total = oBc2 + 32 * 4;
+};
+
+// One layer: NT output tiles, each the chain of KENC encoded-input k-steps and KHID hidden-input k-steps over the (hi, lo)
+// A pieces taken from the weight ring in stream order, three MFMAs per k-step.
+//   EPI 0: out = split(relu(acc / SW)) as the next layer's fragments (saved with their ReLU bits when SAVE)
+//   EPI 1: the sigma head's hidden layer: additionally dot += sum_n relu(acc / SW)[n] * w2[n]
+// Software pipeline pinned with sched_barriers: A pieces are read MCNX3_PF k-steps ahead; the epilogue of tile t (16 work
+// items of <= 9 vector instructions + 4 stores) is issued one item per MFMA gap of tile t + 1, whose accumulator is the
+// other of two register sets and starts at the (scaled) bias.
+template <int W, bool SAVE, int KENC, int KHID, int EPI, int PPW>
+__device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lane,
+                                            const u32x4_t (&ench)[MCN16_ENCKS], const u32x4_t (&encl)[MCN16_ENCKS],
+                                            const u32x4_t (&inh)[W / 16], const u32x4_t (&inl)[W / 16],
+                                            u32x4_t (&outh)[W / 16], u32x4_t (&outl)[W / 16], const float* bias_h,
+                                            const float* w2_h, float& dot, char* save_lane, unsigned* mask_lane) {
+    constexpr int NT = W / 32, KS = W / 16, KTOT = KENC + KHID, F = NT * KTOT, MW = W >= 64 ? W / 64 : 1;
+    constexpr int G = 3 * KTOT;                                   // MFMA gaps per tile
+    constexpr int NIT = 16 + (SAVE ? 4 : 0);                      // work items of one tile's epilogue
+    constexpr int START = G >= NIT + 4 ? 3 : 0;                   // first gap that carries an item (the previous tile's last MFMA must land)
+    constexpr int IPG = (NIT + (G - START) - 1) / (G - START);    // items per gap
+    constexpr int LASTG = START + (NIT + IPG - 1) / IPG - 1;      // gap of the last item
+    constexpr int BIAS_G = (G - 6) > LASTG ? (G - 6) : LASTG;     // the next tile's accumulator (= the set just drained) is loaded here
+    Mcn16Cursor cur;
+    unsigned mw[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) mw[i] = 0u;
+    u32x4_t afh[MCNX3_PF], afl[MCNX3_PF];
+    f32x16 acc[2];
+    unsigned mb = 0u;
+    float v0 = 0.f, v1 = 0.f;
+    unsigned wkeep = 0u;                          // the hi word of the pair in flight between its two items (hipcc 7.2 reads
+                                                  // element 0 when an element of a u32x4 is bit-cast to f16x2: never re-read it from the vector)
+    auto bias_init = [&](f32x16& a, int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {            // accumulator starts at the bias: rows 32t + 8q + 4h + e
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + 32 * t + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[4 * q + e] = b[e];
+        }
+    };
+    // work item i of the epilogue of tile t (accumulator a)
+    auto item = [&](const f32x16& a, int t, int i) {
+        if (i < 16) {
+            const int p = i >> 1;                // packed word p of the tile: registers 2p, 2p + 1
+            if ((i & 1) == 0) {
+                v0 = mcnx3_relu(a[2 * p] * (1.0f / MCNX3_SW));
+                v1 = mcnx3_relu(a[2 * p + 1] * (1.0f / MCNX3_SW));
+                const unsigned w = Mcn16T<false>::pack(v0, v1);
+                wkeep = w;
+                outh[2 * t + (p >> 2)][p & 3] = w;
+                if (SAVE) mb = (p == 0) ? mcn16_nz(w) : ((mb << 1) | mcn16_nz(w));
+                if (EPI == 1) {
+                    const f32x2_t ww = *reinterpret_cast<const f32x2_t*>(w2_h + 32 * t + 8 * (p >> 1) + 2 * (p & 1));
+                    dot = fmaf(v0, ww[0], dot);
+                    dot = fmaf(v1, ww[1], dot);
+                }
+            } else {
+                const f16x2_t hh = __builtin_bit_cast(f16x2_t, wkeep);
+                const f32x2_t back = __builtin_convertvector(hh, f32x2_t);
+                outl[2 * t + (p >> 2)][p & 3] = Mcn16T<false>::pack(v0 - back[0], v1 - back[1]);
+                if (SAVE && p == 7) mw[t >> 1] |= mb << (8 * (t & 1));
+            }
+        } else if (SAVE) {
+            const int k = i - 16;                // 0, 1: hi plane k-steps 2t, 2t + 1; 2, 3: lo plane
+            const int s = 2 * t + (k & 1);
+            if (k < 2) mcn16_ws_store(outh[s], reinterpret_cast<u32x4_t*>(save_lane + s * 1024));
+            else mcn16_ws_store(outl[s], reinterpret_cast<u32x4_t*>(save_lane + (KS + s) * 1024));
+        }
+    };
+    cur.cur = ring.next_off;
+#pragma unroll
+    for (int i = 0; i < MCNX3_PF; ++i)
+        if (i < F) {
+            afh[i] = *reinterpret_cast<const u32x4_t*>(smem + ring.next_off + i * 2048 + lane * 16);
+            afl[i] = *reinterpret_cast<const u32x4_t*>(smem + ring.next_off + i * 2048 + 1024 + lane * 16);
+        }
+    bias_init(acc[0], 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int s = 0; s < KTOT; ++s) {
+            const int f = t * KTOT + s;
+            mcnx3_before_mfma<F, PPW>(ring, cur, f);
+            const u32x4_t a_h = afh[f % MCNX3_PF], a_l = afl[f % MCNX3_PF];
+            if (f + MCNX3_PF < F) {
+                const unsigned o = mcnx3_frag_off(ring, cur, f, f + MCNX3_PF) + lane * 16;
+                afh[f % MCNX3_PF] = *reinterpret_cast<const u32x4_t*>(smem + o);
+                afl[f % MCNX3_PF] = *reinterpret_cast<const u32x4_t*>(smem + o + 1024);
+            }
+            const u32x4_t b_h = s < KENC ? ench[s < KENC ? s : 0] : inh[s >= KENC ? s - KENC : 0];
+            const u32x4_t b_l = s < KENC ? encl[s < KENC ? s : 0] : inl[s >= KENC ? s - KENC : 0];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int gap = 3 * s + g;
+                if (t > 0 && gap >= START) {
+#pragma unroll
+                    for (int i = (gap - START) * IPG; i < (gap - START + 1) * IPG; ++i)
+                        if (i < NIT) item(acc[(t - 1) & 1], t - 1, i);
+                }
+                if (gap == BIAS_G && t + 1 < NT) bias_init(acc[(t + 1) & 1], t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t & 1] = mcnx3_mfma(g == 0 ? a_l : a_h, g == 1 ? b_l : b_h, acc[t & 1]);     // lo*hi, hi*lo, hi*hi
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) item(acc[(NT - 1) & 1], NT - 1, i);
+    if (SAVE) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i) mcn16_ws_store(mw[i], mask_lane + i);
+    }
+}
+
+template <int W, bool SAVE>
+__global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x3_fwd_kernel(Mcn16FwdArgs a) {
+    using SM = FwdX3Smem<W>;
+    constexpr int WAVES = mcnx3_waves(W), ROWS = 32 * WAVES, PPW = 16 / WAVES;
+    constexpr int KS = W / 16, MW = W >= 64 ? W / 64 : 1;
+    constexpr float SXW = MCNX3_SX * MCNX3_SW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int D = a.lay.depth, skip = a.lay.skip;
+    const long long total = a.count ? (long long)min(*a.count, a.max_rows) : (long long)a.n_rays * a.S;
+    if ((long long)blockIdx.x * ROWS >= total) return;
+
+    // ---- once per workgroup: scaled biases, sigma.2 row, scaled sh.2 bias -> LDS (before the ring starts: plain loads drain vmcnt)
+    float* sbias = reinterpret_cast<float*>(smem + SM::oBias);
+    float* sw2 = reinterpret_cast<float*>(smem + SM::oW2);
+    float* sbc2 = reinterpret_cast<float*>(smem + SM::oBc2);
+    for (int l = 0; l < D; ++l)
+        for (int i = tid; i < W; i += 64 * WAVES) sbias[l * W + i] = a.params[a.lay.pB[l] + i] * SXW;
+    for (int i = tid; i < W; i += 64 * WAVES) {
+        sbias[D * W + i] = a.params[a.lay.pBs1 + i] * SXW;
+        sbias[(D + 1) * W + i] = a.params[a.lay.pBc1 + i] * SXW;
+        sw2[i] = a.params[a.lay.pWs2 + i];
+    }
+    if (tid < 32) sbc2[tid] = tid < MCN_NSH ? a.params[a.lay.pBc2 + tid] * SXW : 0.f;
+    const float bs2 = a.params[a.lay.pBs2];
+    float bw[MCN_NFREQ];
+#pragma unroll
+    for (int f = 0; f < MCN_NFREQ; ++f) bw[f] = a.barf_w[f];
+    __syncthreads();
+
+    Mcn16Ring ring;
+    mcnx3_ring_start<PPW>(ring, smem, a.packed, a.stream_slabs, wave, lane);
+
+    const float* bias_h = sbias + 4 * h;
+    const float* w2_h = sw2 + 4 * h;
+
+    for (long long pass = blockIdx.x; pass * ROWS < total; pass += gridDim.x) {
+        const long long tile = pass * WAVES + wave;             // global 32-row tile of this wave
+        const long long g = tile * 32 + m;
+        const bool valid = g < total;
+        const long long gc = valid ? g : total - 1;
+        // ---- per-sample setup (lane-local; both lane halves of a sample compute the same values)
+        int ray, j;
+        if (a.idx) { const int2 rj = a.idx[gc]; ray = rj.x; j = rj.y; }
+        else { ray = (int)(gc / a.S); j = (int)(gc - (long long)ray * a.S); }
+        float zv = a.zgrid[j];
+        if (a.jitter) zv = __fadd_rn(zv, a.jitter[ray]);
+        const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
+        float p[3];
+        p[0] = __fadd_rn(a.rays_o[ray * 3 + 0], __fmul_rn(dx, zv));   // o + d z, two roundings (model/mc_nerf.py:602)
+        p[1] = __fadd_rn(a.rays_o[ray * 3 + 1], __fmul_rn(dy, zv));
+        p[2] = __fadd_rn(a.rays_o[ray * 3 + 2], __fmul_rn(dz, zv));
+        const int addr = ray * a.S + j;
+        u32x4_t ench[MCN16_ENCKS], encl[MCN16_ENCKS];
+        {
+            float E[64];
+            mcnx3_encode_values(p, bw, E);
+#pragma unroll
+            for (int s = 0; s < MCN16_ENCKS; ++s)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int c0 = mcn16_chan(s, 0, 2 * d), c1 = mcn16_chan(s, 0, 2 * d + 1);
+                    unsigned wh, wl;
+                    mcnx3_split2((h ? E[c0 + 4] : E[c0]) * MCNX3_SX, (h ? E[c1 + 4] : E[c1]) * MCNX3_SX, wh, wl);
+                    ench[s][d] = wh; encl[s][d] = wl;
+                }
+        }
+        char* act_lane = SAVE ? reinterpret_cast<char*>(a.act_ws) + (size_t)tile * (2 * KS) * 1024 + lane * 16 : nullptr;
+        unsigned* mask_lane = SAVE ? a.mask_ws + ((size_t)tile * 64 + lane) * MW : nullptr;
+        if (SAVE) {
+            char* e = reinterpret_cast<char*>(a.enc_ws) + (size_t)tile * (2 * MCN16_ENCKS) * 1024 + lane * 16;
+#pragma unroll
+            for (int s = 0; s < MCN16_ENCKS; ++s) {
+                mcn16_ws_store(ench[s], reinterpret_cast<u32x4_t*>(e + s * 1024));
+                mcn16_ws_store(encl[s], reinterpret_cast<u32x4_t*>(e + (MCN16_ENCKS + s) * 1024));
+            }
+        }
+
+        u32x4_t xah[KS], xal[KS], xbh[KS], xbl[KS];
+        float dot = 0.f;
+        // ---- layer 0 (encoded input only), then the trunk; the skip layer takes [encoding, hidden]
+        mcnx3_layer<W, SAVE, MCN16_ENCKS, 0, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h, nullptr, dot, act_lane, mask_lane);
+        for (int l = 1; l < D; ++l) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { xah[s] = xbh[s]; xal[s] = xbl[s]; }
+            char* sl = SAVE ? act_lane + (size_t)l * a.slot_bytes : nullptr;
+            unsigned* ml = SAVE ? mask_lane + (size_t)l * a.mask_slot_words : nullptr;
+            if (l == skip) mcnx3_layer<W, SAVE, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + l * W, nullptr, dot, sl, ml);
+            else mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + l * W, nullptr, dot, sl, ml);
+        }
+        // ---- sigma head: hidden layer on the matrix pipe, the 1-wide output layer lane-local (on the fp32 activations)
+        mcnx3_layer<W, SAVE, 0, KS, 1, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + D * W, w2_h, dot,
+                                            SAVE ? act_lane + (size_t)D * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)D * a.mask_slot_words : nullptr);
+        // ---- SH head: hidden layer (reads the same trunk output), then the 27 (32) coefficient rows
+        mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + (D + 1) * W, nullptr, dot,
+                                            SAVE ? act_lane + (size_t)(D + 1) * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)(D + 1) * a.mask_slot_words : nullptr);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sbc2 + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * q + e] = b[e];
+        }
+        {
+            Mcn16Cursor cur;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                mcnx3_before_mfma<KS, PPW>(ring, cur, s);
+                const unsigned o = cur.cur + (s & (MCNX3_SLABF - 1)) * 2048 + lane * 16;
+                const u32x4_t a_h = *reinterpret_cast<const u32x4_t*>(smem + o);
+                const u32x4_t a_l = *reinterpret_cast<const u32x4_t*>(smem + o + 1024);
+                mcnx3_mfma3(acc, a_h, a_l, xah[s], xal[s]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] *= 1.0f / SXW;
+        if (SAVE) {          // the SH coefficients (bias included) for the backward's view-direction term: the fp32 accumulator tile
+            char* e = reinterpret_cast<char*>(a.sh_ws) + (size_t)tile * 4096 + lane * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                mcn16_ws_store(f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]}, reinterpret_cast<f32x4*>(e + q * 1024));
+        }
+        // ---- per-sample epilogue: sigma, SH colour (model/net_utils.py:154-169), sigmoid.  Register 4q + e of this lane
+        //      is SH row n = 8q + 4h + e = 9 c + i (colour c, basis i); the two lane halves hold complementary rows.
+        float bas[9];
+        mcn_sh_basis(dx, dy, dz, bas);
+        float pre[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n0 = 8 * (r >> 2) + (r & 3), n1 = n0 + 4;
+            const float b0 = n0 < MCN_NSH ? bas[n0 % 9] : 0.f, b1 = n1 < MCN_NSH ? bas[n1 % 9] : 0.f;
+            const float contrib = acc[r] * (h ? b1 : b0);
+            const int c0 = n0 / 9, c1 = n1 / 9;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const bool in0 = n0 < MCN_NSH && c0 == c, in1 = n1 < MCN_NSH && c1 == c;
+                if (in0 && in1) pre[c] += contrib;
+                else if (in0) pre[c] += h ? 0.f : contrib;
+                else if (in1) pre[c] += h ? contrib : 0.f;
+            }
+        }
+        const float sigma = (dot + __shfl_xor(dot, 32)) * (1.0f / MCNX3_SX) + bs2;
+        f32x4 o;
+        o[0] = sigma;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float pc = pre[c] + __shfl_xor(pre[c], 32);
+            o[1 + c] = 1.0f / (1.0f + expf(-pc));
+        }
+        if (valid && h == 0) *reinterpret_cast<f32x4*>(a.out + (size_t)addr * 4) = o;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ring pieces still in flight must land before the LDS is released
+}
+
+template <int W>
+static hipError_t launch_fwd_x3(const Mcn16FwdArgs& a, long long max_rows, hipStream_t st) {
+    using SM = FwdX3Smem<W>;
+    constexpr int WAVES = mcnx3_waves(W), ROWS = 32 * WAVES;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    long long passes = (max_rows + ROWS - 1) / ROWS;
+    if (passes <= 0) return hipSuccess;
+    const int grid = (int)(passes < cus ? passes : cus);
+    const bool save = a.act_ws != nullptr;
+    void (*kern)(Mcn16FwdArgs) = save ? mlp_x3_fwd_kernel<W, true> : mlp_x3_fwd_kernel<W, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), SM::total, st, a);
+    return hipGetLastError();
+}
+
+hipError_t mcnx3_launch_fwd(const Mcn16FwdArgs& a, hipStream_t st) {
+    const long long max_rows = a.count ? (long long)a.max_rows : (long long)a.n_rays * a.S;
+    switch (a.lay.width) {
+        case 256: return launch_fwd_x3<256>(a, max_rows, st);
+        case 128: return launch_fwd_x3<128>(a, max_rows, st);
+        case 64:  return launch_fwd_x3<64>(a, max_rows, st);
+        case 32:  return launch_fwd_x3<32>(a, max_rows, st);
+    }
+    return hipErrorInvalidValue;
+}

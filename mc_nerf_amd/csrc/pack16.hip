@@ -49,3 +49,56 @@ hipError_t mcn16_launch_pack(const McnLayout& L, const float* params, void* pack
     else hipLaunchKernelGGL(pack16_kernel<false>, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd);
     return hipGetLastError();
 }
+
+// ---- split-f16 ("f16x3") streams (mcnerf_x3.h): per logical fragment the hi piece (f16(w SW)) then the lo piece
+//      (f16(w SW - hi)), segments padded to whole slabs of 8 logical fragments.
+#include "mcnerf_x3.h"
+__global__ void packx3_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __restrict__ params, char* __restrict__ pf, char* __restrict__ pb) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nf = sf.total_frags * 64, nb = sb.total_frags * 64;
+    if (gid >= nf + nb) return;
+    const bool bwd = gid >= nf;
+    const Mcn16Stream& st = bwd ? sb : sf;
+    const int id = bwd ? gid - nf : gid;
+    const int frag = id >> 6, lane = id & 63;
+    const int i = lane & 31, h = lane >> 5;
+    int s = 0;
+    while (s + 1 < st.nseg && frag >= st.seg[s + 1].first_frag) ++s;
+    const Mcn16Seg sg = st.seg[s];
+    const int loc = frag - sg.first_frag;
+    const int per_tile = sg.a.ksteps + sg.b.ksteps;
+    const int t = loc / per_tile, ks = loc - t * per_tile;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (t < sg.tiles) {
+        const bool inb = ks >= sg.a.ksteps;
+        const Mcn16Part p = inb ? sg.b : sg.a;
+        const int kk = inb ? ks - sg.a.ksteps : ks;
+        const int o = 32 * t + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = mcn16_chan(kk, h, j);
+            if (o < p.out_real && c < p.con_real)
+                v[j] = sg.transposed ? params[p.src + (size_t)c * p.ld + p.col0 + o] : params[p.src + (size_t)o * p.ld + p.col0 + c];
+        }
+    }
+    u32x4_t wh, wl;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        unsigned a, b;
+        mcnx3_split2(v[2 * d] * MCNX3_SW, v[2 * d + 1] * MCNX3_SW, a, b);
+        wh[d] = a; wl[d] = b;
+    }
+    char* dst = (bwd ? pb : pf) + (size_t)frag * 2048 + lane * 16;
+    *reinterpret_cast<u32x4_t*>(dst) = wh;
+    *reinterpret_cast<u32x4_t*>(dst + 1024) = wl;
+}
+
+hipError_t mcnx3_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, hipStream_t st) {
+    const Mcn16Stream sf = mcnx3_fwd_stream(L), sb = mcnx3_bwd_stream(L);
+    const int total = (sf.total_frags + sb.total_frags) * 64;
+    const int threads = 256, grid = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(packx3_kernel, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd);
+    return hipGetLastError();
+}

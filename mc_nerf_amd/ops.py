@@ -99,18 +99,19 @@ def flatten_params(net: Net, tensors, device) -> Tensor:
 
 
 # --------------------------------------------------------------------------- ops
-PRECISIONS = ("f32", "f16x3", "f16", "bf16")
-# single-pass 16-bit MFMA modes (csrc/mcnerf_16.h): name -> dtype code of the C ABI
-DTYPE16 = {"f16": 0, "bf16": 1}
+PRECISIONS = ("f32", "f16x3", "f16", "bf16", "f16x3r1")
+# register-chain modes: single-pass 16-bit MFMA (csrc/mcnerf_16.h) and split-f16 "f16x3" (csrc/mcnerf_x3.h): name -> dtype
+# code of the C ABI.  ("f16x3r1" = the round-1 split-f16 kernels, kept for A/B measurements only)
+DTYPE16 = {"f16": 0, "bf16": 1, "f16x3": 2}
 
 
 def is16(precision: str) -> bool:
     return precision in DTYPE16
 
 
-def packed16_split(net: Net, packed: Tensor):
-    """The 16-bit modes keep both fragment streams of a net in ONE byte tensor: (forward stream, backward stream) views."""
-    nf = int(_lib.lib().mcnerf_packed_bytes_16(*net.triple, 0))
+def packed16_split(net: Net, packed: Tensor, precision: str):
+    """The register-chain modes keep both fragment streams of a net in ONE byte tensor: (forward stream, backward stream) views."""
+    nf = int(_lib.lib().mcnerf_packed_bytes_16(*net.triple, DTYPE16[precision], 0))
     return packed[:nf], packed[nf:]
 
 
@@ -121,14 +122,15 @@ def pack_weights(net: Net, params: Tensor, packed=None, precision: str = "f32"):
     if is16(precision):
         if packed is None:
             l = _lib.lib()
-            packed = torch.empty(int(l.mcnerf_packed_bytes_16(*net.triple, 0)) + int(l.mcnerf_packed_bytes_16(*net.triple, 1)),
+            dt = DTYPE16[precision]
+            packed = torch.empty(int(l.mcnerf_packed_bytes_16(*net.triple, dt, 0)) + int(l.mcnerf_packed_bytes_16(*net.triple, dt, 1)),
                                  dtype=torch.uint8, device=params.device)
-        pf, pb = packed16_split(net, packed)
+        pf, pb = packed16_split(net, packed, precision)
         _lib.call("mcnerf_pack_weights_16", *net.triple, _p(params), _p(pf, torch.uint8), _p(pb, torch.uint8), DTYPE16[precision], _stream())
         return packed
     if packed is None:
         packed = torch.empty(packed_count(net), dtype=torch.float32, device=params.device)
-    name = "mcnerf_pack_weights" if precision == "f32" else "mcnerf_pack_weights_f16x3"
+    name = "mcnerf_pack_weights" if precision == "f32" else "mcnerf_pack_weights_f16x3"      # ("f16x3r1")
     _lib.call(name, *net.triple, _p(params), _p(packed), _stream())
     return packed
 
@@ -160,18 +162,18 @@ class MlpSave:
     mask: Tensor
 
 
-def ws_bytes_16(net: Net, capacity: int, which: int) -> int:
-    return int(_lib.lib().mcnerf_ws_bytes_16(net.depth, net.width, int(capacity), which))
+def ws_bytes_16(net: Net, capacity: int, which: int, precision: str = "f16") -> int:
+    return int(_lib.lib().mcnerf_ws_bytes_16(net.depth, net.width, DTYPE16[precision], int(capacity), which))
 
 
 def alloc_save(net: Net, capacity: int, device, precision: str = "f32") -> MlpSave:
     capacity = max(int(capacity), 1)
     if is16(precision):
         return MlpSave(capacity,
-                       torch.empty(ws_bytes_16(net, capacity, 0), dtype=torch.uint8, device=device),
-                       torch.empty(ws_bytes_16(net, capacity, 1), dtype=torch.uint8, device=device),
-                       torch.empty(ws_bytes_16(net, capacity, 4), dtype=torch.uint8, device=device),
-                       torch.empty(ws_bytes_16(net, capacity, 2) // 4, dtype=torch.int32, device=device))
+                       torch.empty(ws_bytes_16(net, capacity, 0, precision), dtype=torch.uint8, device=device),
+                       torch.empty(ws_bytes_16(net, capacity, 1, precision), dtype=torch.uint8, device=device),
+                       torch.empty(ws_bytes_16(net, capacity, 4, precision), dtype=torch.uint8, device=device),
+                       torch.empty(ws_bytes_16(net, capacity, 2, precision) // 4, dtype=torch.int32, device=device))
     return MlpSave(capacity,
                    torch.empty((net.depth + 2) * capacity * net.width, dtype=torch.float32, device=device),
                    torch.empty(capacity * 64, dtype=torch.float32, device=device),
@@ -186,7 +188,7 @@ def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
     n_rays, S = rays_d.shape[0], zgrid.numel()
     assert out.numel() == n_rays * S * 4
     if is16(precision):
-        _lib.call("mcnerf_mlp_fwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed16_split(net, packed)[0], torch.uint8), _p(rays_o), _p(rays_d),
+        _lib.call("mcnerf_mlp_fwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed16_split(net, packed, precision)[0], torch.uint8), _p(rays_o), _p(rays_d),
                   _p(zgrid), _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
                   _p(out), _p(save.act, torch.uint8) if save else None, save.capacity if save else 0,
                   _p(save.enc, torch.uint8) if save else None, _p(save.mask, torch.int32) if save else None,
@@ -242,7 +244,7 @@ def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
             precision: str = "f32", gmax: Optional[Tensor] = None) -> None:
     n_rays, S = rays_d.shape[0], zgrid.numel()
     if is16(precision):
-        _lib.call("mcnerf_mlp_bwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed16_split(net, packed)[1], torch.uint8), _p(rays_o), _p(rays_d),
+        _lib.call("mcnerf_mlp_bwd_16", *net.triple, DTYPE16[precision], _p(params), _p(packed16_split(net, packed, precision)[1], torch.uint8), _p(rays_o), _p(rays_d),
                   _p(zgrid), _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
                   _p(out), _p(d_out), _p(save.mask, torch.int32), save.capacity, _p(save.enc, torch.uint8), _p(save.sh, torch.uint8),
                   _p(dy, torch.uint8), _p(dsh, torch.uint8), _p(d_rays_o), _p(d_rays_d), _p(gmax, torch.int32), _stream())
@@ -410,15 +412,20 @@ def alloc_grad_ws(net: Net, save: MlpSave, precision: str):
     """dy / dsh workspaces of mlp_bwd for the precision mode."""
     if is16(precision):
         return (torch.empty_like(save.act),
-                torch.empty(ws_bytes_16(net, save.capacity, 3), dtype=torch.uint8, device=save.act.device))
+                torch.empty(ws_bytes_16(net, save.capacity, 3, precision), dtype=torch.uint8, device=save.act.device))
     return torch.empty_like(save.act), torch.empty_like(save.sh)
 
 
 def decode_frags_16(buf: Tensor, n_slots: int, width: int, rows: int, precision: str = "f16") -> Tensor:
-    """Fragment-major 16-bit workspace (csrc/mcnerf_16.h) -> [n_slots, rows, width] fp32.  Debug / test helper."""
+    """Fragment-major workspace of the register-chain modes (csrc/mcnerf_16.h, mcnerf_x3.h) -> [n_slots, rows, width] fp32
+    (f16x3: hi + lo, still carrying the kernel's power-of-two scale: SPLIT_SCALE_X for activations).  Debug / test helper."""
     ks = width // 16
-    dt = torch.float16 if precision == "f16" else torch.bfloat16
-    x = buf.view(dt).view(n_slots, -1, ks, 2, 32, 8)            # [slot][tile][k-step][h][m][j]
+    if precision == "f16x3":                                    # [slot][tile][part hi / lo][k-step][h][m][j], value = hi + lo
+        x2 = buf.view(torch.float16).view(n_slots, -1, 2, ks, 2, 32, 8).float()
+        x = x2[:, :, 0] + x2[:, :, 1]
+    else:
+        dt = torch.float16 if precision == "f16" else torch.bfloat16
+        x = buf.view(dt).view(n_slots, -1, ks, 2, 32, 8)        # [slot][tile][k-step][h][m][j]
     tiles = x.shape[1]
     s_, h_, j_ = torch.meshgrid(torch.arange(ks), torch.arange(2), torch.arange(8), indexing="ij")
     chan = (16 * s_ + 8 * (j_ // 4) + 4 * h_ + (j_ % 4)).reshape(-1).to(buf.device)       # channel of (s, h, j)
@@ -446,7 +453,14 @@ def decode_masks_16(mask: Tensor, n_slots: int, width: int, rows: int) -> Tensor
     return out.reshape(n_slots, tiles * 32, width)[:, :rows]
 
 
-SPLIT_SCALE_X = 8.0      # MCN_SX of csrc/mcnerf_h.h
+SPLIT_SCALE_X = 8.0      # MCN_SX of csrc/mcnerf_h.h = MCNX3_SX of csrc/mcnerf_x3.h
+
+
+def decode_sh_x3(buf: Tensor, rows: int) -> Tensor:
+    """sh.2 outputs saved by the f16x3 forward (the fp32 accumulator tile: [tile][q][lane = 32 h + m][4]) -> [rows, 32]:
+    register 4 q + e of lane (m, h) is SH row 8 q + 4 h + e.  Debug / test helper."""
+    x = buf.view(torch.float32).view(-1, 4, 2, 32, 4)            # [tile][q][h][m][e]
+    return x.permute(0, 3, 1, 2, 4).reshape(-1, 32)[:rows]       # [tile, m][q, h, e] -> row 8 q + 4 h + e
 
 
 def decode_split_words(t: Tensor, scale: float = SPLIT_SCALE_X) -> Tensor:
