@@ -25,8 +25,12 @@
 #define MCNX3_PF 2                     // A fragments (pairs) read this many k-steps ahead of their MFMAs
 #endif
 
-// waves per workgroup by net width (the wave count decides rows per pass and ring pieces per wave)
-static inline constexpr int mcnx3_waves(int width) { return width >= 256 ? 4 : 8; }
+// waves per workgroup by net width (the wave count decides rows per pass and ring pieces per wave): nets at least
+// MCNX3_WIDE_MIN wide run one wave per SIMD with 512 registers per lane
+#ifndef MCNX3_WIDE_MIN
+#define MCNX3_WIDE_MIN 128
+#endif
+static inline constexpr int mcnx3_waves(int width) { return width >= MCNX3_WIDE_MIN ? 4 : 8; }
 
 static inline int mcnx3_pad(int frags) { return (frags + MCNX3_SLABF - 1) / MCNX3_SLABF * MCNX3_SLABF; }
 // The 16-bit streams with the segments padded to whole x3 slabs (first_frag / total_frags count LOGICAL fragments of 2 KiB).

@@ -422,18 +422,23 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
                 red[3 + c] = (dp * zv + dd) * inv_sg;              // d direction: through x = o + d z, plus the SH term
             }
             settle();
-            // segmented inclusive scan over the 32 samples (rows of one ray are contiguous): the last row of each run adds
-            // the run's sum with 6 atomics instead of 6 per sample
+            // segmented inclusive scan over the 32 samples: a run = consecutive rows of one ray (the rows of a ray are contiguous in
+            // the selection order; after the random cap, model/mc_nerf.py:630-632, they need not be: equal keys that are not
+            // adjacent are separate runs, so the scan carries head flags instead of comparing keys at a distance).  The last
+            // row of each run adds the run's sum with 6 atomics instead of 6 per sample.
             const int rkey = valid ? ray : -1;
+            const int rprev = __shfl_up(rkey, 1, 32);
+            int head = (m == 0 || rprev != rkey) ? 1 : 0;
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) {
-                const int rk = __shfl_up(rkey, off, 32);
-                const bool take = (m >= off) && rk == rkey;
+                const int hup = __shfl_up(head, off, 32);
+                const bool take = (m >= off) && !head;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     const float up = __shfl_up(red[c], off, 32);
                     red[c] += take ? up : 0.f;
                 }
+                if (m >= off) head |= hup;
             }
             const int rnext = __shfl_down(rkey, 1, 32);
             if (h == 0 && valid && (m == 31 || rnext != rkey)) {

@@ -311,10 +311,8 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         if (D >= 3) mask_issue(mask_lane, D - 3, buf_of(D - 3));          // buffer 1 is free (sh.2^T is done)
         if (MASK_DMA) mask_read(mask_lane, mk_t, 2, D - 1);
         mcnx3_bwd_seg<W, KS, NT, 2, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, dy_lane + (size_t)(D - 1) * a.slot_bytes);
-        // ---- trunk, last layer to first: xb = dY_l
-        for (int l = D - 1; l >= 1; --l) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { xah[s] = xbh[s]; xal[s] = xbl[s]; }
+        // ---- trunk, last layer to first, two layers per trip (dY_l in xb -> dY_{l-1} in xa -> dY_{l-2} in xb: no copies between layers)
+        auto trunk_masks = [&](int l) {
             if (MASK_DMA) {
                 if (l >= 3) mask_issue(mask_lane, l - 3, buf_of(l - 3));  // the buffer of slot l (previous segment) is free
                 mask_read(mask_lane, mk_t, buf_of(l - 1), l - 1);
@@ -328,8 +326,19 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
                 mask_issue(mln, D, 0); mask_issue(mln, D + 1, 1); mask_issue(mln, D - 1, 2);
                 if (!MASK_DMA) { mask_read(mln, mk0_s, 0, D); mask_read(mln, mk0_c, 1, D + 1); mask_read(mln, mk0_t, 2, D - 1); }
             }
-            if (l == skip) mcnx3_bwd_seg<W, KS, 2, 3, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, nullptr);      // encoded columns of the skip layer
-            mcnx3_bwd_seg<W, KS, NT, 1, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, dy_lane + (size_t)(l - 1) * a.slot_bytes);
+        };
+        for (int l = D - 1; l >= 1; l -= 2) {
+            trunk_masks(l);
+            if (l == skip) mcnx3_bwd_seg<W, KS, 2, 3, PPW>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, nullptr);      // encoded columns of the skip layer
+            mcnx3_bwd_seg<W, KS, NT, 1, PPW>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, dy_lane + (size_t)(l - 1) * a.slot_bytes);
+            if (l - 1 >= 1) {
+                trunk_masks(l - 1);
+                if (l - 1 == skip) mcnx3_bwd_seg<W, KS, 2, 3, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, nullptr);
+                mcnx3_bwd_seg<W, KS, NT, 1, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, dy_lane + (size_t)(l - 2) * a.slot_bytes);
+            } else {               // an even trunk depth ends in xa: one copy per pass
+#pragma unroll
+                for (int s = 0; s < KS; ++s) { xbh[s] = xah[s]; xbl[s] = xal[s]; }
+            }
         }
         // ---- the next pass's rows: index pair from LDS (DMA'd during this pass's prologue), gathers land under the last GEMM and the epilogue
         In nxt;
@@ -415,18 +424,23 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
                 red[3 + c] = (dp * zv + dd) * inv_sg;              // d direction: through x = o + d z, plus the SH term
             }
             settle();
-            // segmented inclusive scan over the 32 samples (rows of one ray are contiguous): the last row of each run adds
-            // the run's sum with 6 atomics instead of 6 per sample
+            // segmented inclusive scan over the 32 samples: a run = consecutive rows of one ray (the rows of a ray are contiguous in
+            // the selection order; after the random cap, model/mc_nerf.py:630-632, they need not be: equal keys that are not
+            // adjacent are separate runs, so the scan carries head flags instead of comparing keys at a distance).  The last
+            // row of each run adds the run's sum with 6 atomics instead of 6 per sample.
             const int rkey = valid ? ray : -1;
+            const int rprev = __shfl_up(rkey, 1, 32);
+            int head = (m == 0 || rprev != rkey) ? 1 : 0;
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) {
-                const int rk = __shfl_up(rkey, off, 32);
-                const bool take = (m >= off) && rk == rkey;
+                const int hup = __shfl_up(head, off, 32);
+                const bool take = (m >= off) && !head;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     const float up = __shfl_up(red[c], off, 32);
                     red[c] += take ? up : 0.f;
                 }
+                if (m >= off) head |= hup;
             }
             const int rnext = __shfl_down(rkey, 1, 32);
             if (h == 0 && valid && (m == 31 || rnext != rkey)) {

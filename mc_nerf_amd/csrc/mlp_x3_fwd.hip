@@ -13,7 +13,9 @@ struct FwdX3Smem {
     static constexpr int oBias = MCN16_RING * MCN16_SLAB * 1024;   // fp32 [MAXD + 2][W]: trunk, sigma.0, sh.0 biases x (SX SW)
     static constexpr int oW2 = oBias + (MCN_MAXD + 2) * W * 4;     // sigma.2 weight row [W]
     static constexpr int oBc2 = oW2 + W * 4;                        // sh.2 bias [32] (27 + zero pad) x (SX SW)
-    static constexpr int total = oBc2 + 32 * 4;
+    static constexpr int oIdx = oBc2 + 32 * 4;                      // per wave: the NEXT pass's (ray, sample) pairs [32][2] (LDS-DMA)
+    static constexpr int oIn = oIdx + mcnx3_waves(W) * 256;         // per wave: the next pass's per-sample inputs, 8 x [64 lanes] dwords (LDS-DMA gathers)
+    static constexpr int total = oIn + mcnx3_waves(W) * 8 * 256;
 };
 
 // One layer: NT output tiles, each the chain of KENC encoded-input k-steps and KHID hidden-input k-steps over the (hi, lo)
@@ -31,7 +33,9 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
                                             const float* w2_h, float& dot, char* save_lane, unsigned* mask_lane) {
     constexpr int NT = W / 32, KS = W / 16, KTOT = KENC + KHID, F = NT * KTOT, MW = W >= 64 ? W / 64 : 1;
     constexpr int G = 3 * KTOT;                                   // MFMA gaps per tile
-    constexpr int NIT = 16 + (SAVE ? 4 : 0);                      // work items of one tile's epilogue
+    constexpr bool HAS2 = SAVE || EPI == 1;                       // a word has a second item (ReLU bit, sigma dot)
+    constexpr int IPW = HAS2 ? 3 : 2;                             // items per packed word
+    constexpr int NIT = 8 * IPW + (SAVE ? 4 : 0);                 // work items of one tile's epilogue (each <= 6 vector instructions)
     constexpr int START = G >= NIT + 4 ? 3 : 0;                   // first gap that carries an item (the previous tile's last MFMA must land)
     constexpr int IPG = (NIT + (G - START) - 1) / (G - START);    // items per gap
     constexpr int LASTG = START + (NIT + IPG - 1) / IPG - 1;      // gap of the last item
@@ -56,28 +60,31 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
     };
     // work item i of the epilogue of tile t (accumulator a)
     auto item = [&](const f32x16& a, int t, int i) {
-        if (i < 16) {
-            const int p = i >> 1;                // packed word p of the tile: registers 2p, 2p + 1
-            if ((i & 1) == 0) {
+        if (i < 8 * IPW) {
+            const int p = i / IPW, ph = i % IPW;  // packed word p of the tile: registers 2p, 2p + 1
+            if (ph == 0) {
                 v0 = mcnx3_relu(a[2 * p] * (1.0f / MCNX3_SW));
                 v1 = mcnx3_relu(a[2 * p + 1] * (1.0f / MCNX3_SW));
                 const unsigned w = Mcn16T<false>::pack(v0, v1);
                 wkeep = w;
                 outh[2 * t + (p >> 2)][p & 3] = w;
-                if (SAVE) mb = (p == 0) ? mcn16_nz(w) : ((mb << 1) | mcn16_nz(w));
+            } else if (ph == IPW - 1) {
+                const f16x2_t hh = __builtin_bit_cast(f16x2_t, wkeep);
+                const f32x2_t back = __builtin_convertvector(hh, f32x2_t);
+                outl[2 * t + (p >> 2)][p & 3] = Mcn16T<false>::pack(v0 - back[0], v1 - back[1]);
+            } else {
+                if (SAVE) {
+                    mb = (p == 0) ? mcn16_nz(wkeep) : ((mb << 1) | mcn16_nz(wkeep));
+                    if (p == 7) mw[t >> 1] |= mb << (8 * (t & 1));
+                }
                 if (EPI == 1) {
                     const f32x2_t ww = *reinterpret_cast<const f32x2_t*>(w2_h + 32 * t + 8 * (p >> 1) + 2 * (p & 1));
                     dot = fmaf(v0, ww[0], dot);
                     dot = fmaf(v1, ww[1], dot);
                 }
-            } else {
-                const f16x2_t hh = __builtin_bit_cast(f16x2_t, wkeep);
-                const f32x2_t back = __builtin_convertvector(hh, f32x2_t);
-                outl[2 * t + (p >> 2)][p & 3] = Mcn16T<false>::pack(v0 - back[0], v1 - back[1]);
-                if (SAVE && p == 7) mw[t >> 1] |= mb << (8 * (t & 1));
             }
         } else if (SAVE) {
-            const int k = i - 16;                // 0, 1: hi plane k-steps 2t, 2t + 1; 2, 3: lo plane
+            const int k = i - 8 * IPW;           // 0, 1: hi plane k-steps 2t, 2t + 1; 2, 3: lo plane
             const int s = 2 * t + (k & 1);
             if (k < 2) mcn16_ws_store(outh[s], reinterpret_cast<u32x4_t*>(save_lane + s * 1024));
             else mcn16_ws_store(outl[s], reinterpret_cast<u32x4_t*>(save_lane + (KS + s) * 1024));
@@ -159,6 +166,39 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
     for (int f = 0; f < MCN_NFREQ; ++f) bw[f] = a.barf_w[f];
     __syncthreads();
 
+    // ---- per-sample inputs.  On the wide net (one wave per SIMD: nothing else covers a memory round trip) they are
+    // fetched ONE PASS AHEAD by LDS-DMA, invisible to the compiler's vmcnt bookkeeping (an ordinary load would make hipcc
+    // drain the weight ring at its first use): the next pass's (ray, sample) pairs right after this pass's prologue, the
+    // gathers through them in front of the SH head; explicit counted waits (at most PPW * AHEAD operations are ever younger
+    // than something issued a whole layer earlier) guarantee the landing.
+    constexpr bool PREF = WAVES == 4;
+    const unsigned idx_lds = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem) + SM::oIdx + wave * 256;
+    const unsigned in_lds = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem) + SM::oIn + wave * (8 * 256);
+    const float* in_rd = reinterpret_cast<const float*>(smem + SM::oIn + wave * (8 * 256)) + lane;
+    auto row_of = [&](long long pass_) -> long long {           // this lane's row of a pass, clamped into the list
+        const long long g_ = (pass_ * WAVES + wave) * 32 + m;
+        return g_ < total ? g_ : total - 1;
+    };
+    auto gather_dma = [&](int ray_, int j_) {
+        mcn16_dma4(a.zgrid + j_, in_lds);
+        if (a.jitter) mcn16_dma4(a.jitter + ray_, in_lds + 256);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            mcn16_dma4(a.rays_d + ray_ * 3 + c, in_lds + (2 + c) * 256);
+            mcn16_dma4(a.rays_o + ray_ * 3 + c, in_lds + (5 + c) * 256);
+        }
+    };
+    int ray_n = 0, j_n = 0;                                     // (ray, sample) of this lane's row of the coming pass
+    {
+        const long long gc0 = row_of(blockIdx.x);
+        if (a.idx) { const int2 rj = a.idx[gc0]; ray_n = rj.x; j_n = rj.y; }
+        else { ray_n = (int)(gc0 / a.S); j_n = (int)(gc0 - (long long)ray_n * a.S); }
+        if (PREF) {
+            gather_dma(ray_n, j_n);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+
     Mcn16Ring ring;
     mcnx3_ring_start<PPW>(ring, smem, a.packed, a.stream_slabs, wave, lane);
 
@@ -170,17 +210,33 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         const long long g = tile * 32 + m;
         const bool valid = g < total;
         const long long gc = valid ? g : total - 1;
+        const long long pass_n = pass + gridDim.x;
         // ---- per-sample setup (lane-local; both lane halves of a sample compute the same values)
         int ray, j;
-        if (a.idx) { const int2 rj = a.idx[gc]; ray = rj.x; j = rj.y; }
-        else { ray = (int)(gc / a.S); j = (int)(gc - (long long)ray * a.S); }
-        float zv = a.zgrid[j];
-        if (a.jitter) zv = __fadd_rn(zv, a.jitter[ray]);
-        const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
+        float zv, dx, dy, dz, ox, oy, oz;
+        if (PREF) {
+            ray = ray_n; j = j_n;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * MCN16_AHEAD) : "memory");
+            zv = in_rd[0];
+            if (a.jitter) zv = __fadd_rn(zv, in_rd[64]);
+            dx = in_rd[2 * 64]; dy = in_rd[3 * 64]; dz = in_rd[4 * 64];
+            ox = in_rd[5 * 64]; oy = in_rd[6 * 64]; oz = in_rd[7 * 64];
+        } else {
+            if (a.idx) { const int2 rj = a.idx[gc]; ray = rj.x; j = rj.y; }
+            else { ray = (int)(gc / a.S); j = (int)(gc - (long long)ray * a.S); }
+            zv = a.zgrid[j];
+            if (a.jitter) zv = __fadd_rn(zv, a.jitter[ray]);
+            dx = a.rays_d[ray * 3 + 0]; dy = a.rays_d[ray * 3 + 1]; dz = a.rays_d[ray * 3 + 2];
+            ox = a.rays_o[ray * 3 + 0]; oy = a.rays_o[ray * 3 + 1]; oz = a.rays_o[ray * 3 + 2];
+        }
         float p[3];
-        p[0] = __fadd_rn(a.rays_o[ray * 3 + 0], __fmul_rn(dx, zv));   // o + d z, two roundings (model/mc_nerf.py:602)
-        p[1] = __fadd_rn(a.rays_o[ray * 3 + 1], __fmul_rn(dy, zv));
-        p[2] = __fadd_rn(a.rays_o[ray * 3 + 2], __fmul_rn(dz, zv));
+        p[0] = __fadd_rn(ox, __fmul_rn(dx, zv));   // o + d z, two roundings (model/mc_nerf.py:602)
+        p[1] = __fadd_rn(oy, __fmul_rn(dy, zv));
+        p[2] = __fadd_rn(oz, __fmul_rn(dz, zv));
+        if (PREF && a.idx) {       // lane L fetches dword L of the next pass's 32 (ray, sample) pairs
+            const long long gn = (pass_n * WAVES + wave) * 32 + (lane >> 1);
+            mcn16_dma4(reinterpret_cast<const int*>(a.idx) + 2 * (gn < total ? gn : total - 1) + (lane & 1), idx_lds);
+        }
         const int addr = ray * a.S + j;
         u32x4_t ench[MCN16_ENCKS], encl[MCN16_ENCKS];
         {
@@ -209,19 +265,38 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
 
         u32x4_t xah[KS], xal[KS], xbh[KS], xbl[KS];
         float dot = 0.f;
-        // ---- layer 0 (encoded input only), then the trunk; the skip layer takes [encoding, hidden]
+        // ---- layer 0 (encoded input only), then the trunk two layers per trip (xb -> xa -> xb: no copies between layers);
+        //      the skip layer takes [encoding, hidden]
         mcnx3_layer<W, SAVE, MCN16_ENCKS, 0, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h, nullptr, dot, act_lane, mask_lane);
-        for (int l = 1; l < D; ++l) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { xah[s] = xbh[s]; xal[s] = xbl[s]; }
+        for (int l = 1; l < D; l += 2) {
             char* sl = SAVE ? act_lane + (size_t)l * a.slot_bytes : nullptr;
             unsigned* ml = SAVE ? mask_lane + (size_t)l * a.mask_slot_words : nullptr;
-            if (l == skip) mcnx3_layer<W, SAVE, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + l * W, nullptr, dot, sl, ml);
-            else mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + l * W, nullptr, dot, sl, ml);
+            if (l == skip) mcnx3_layer<W, SAVE, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + l * W, nullptr, dot, sl, ml);
+            else mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + l * W, nullptr, dot, sl, ml);
+            if (l + 1 < D) {
+                sl = SAVE ? act_lane + (size_t)(l + 1) * a.slot_bytes : nullptr;
+                ml = SAVE ? mask_lane + (size_t)(l + 1) * a.mask_slot_words : nullptr;
+                if (l + 1 == skip) mcnx3_layer<W, SAVE, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + (l + 1) * W, nullptr, dot, sl, ml);
+                else mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + (l + 1) * W, nullptr, dot, sl, ml);
+            } else {               // an even trunk depth ends in xa: one copy per pass
+#pragma unroll
+                for (int s = 0; s < KS; ++s) { xbh[s] = xah[s]; xbl[s] = xal[s]; }
+            }
         }
         // ---- sigma head: hidden layer on the matrix pipe, the 1-wide output layer lane-local (on the fp32 activations)
         mcnx3_layer<W, SAVE, 0, KS, 1, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + D * W, w2_h, dot,
                                             SAVE ? act_lane + (size_t)D * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)D * a.mask_slot_words : nullptr);
+        if (PREF) {                // the coming pass's rows: index pair from LDS, gathers by LDS-DMA (landed long before the pass ends)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * MCN16_AHEAD) : "memory");
+            if (a.idx) {
+                const int2 rj = *reinterpret_cast<const int2*>(smem + SM::oIdx + wave * 256 + m * 8);
+                ray_n = rj.x; j_n = rj.y;
+            } else {
+                const long long gn = row_of(pass_n);
+                ray_n = (int)(gn / a.S); j_n = (int)(gn - (long long)ray_n * a.S);
+            }
+            gather_dma(ray_n, j_n);
+        }
         // ---- SH head: hidden layer (reads the same trunk output), then the 27 (32) coefficient rows
         mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + (D + 1) * W, nullptr, dot,
                                             SAVE ? act_lane + (size_t)(D + 1) * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)(D + 1) * a.mask_slot_words : nullptr);
