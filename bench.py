@@ -13,8 +13,10 @@ all-reduce (N > 1) -> RAdam step.  Inputs are resident in HBM before the timed r
 `--gpus N` with N > 1 and no torchrun environment: this process (which never touches the GPU) starts N fresh rank
 processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and waits for them; under
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks are the given processes.
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement"): the headline precision mode (`--precision`) timed for
-`--steps` steps, plus `by_precision` with the other modes of `--also` timed in the same run on fewer steps.
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement"): the headline precision mode (`--precision`; default the
+fp32-grade split-f16 mode `f16x3`: the reference's arithmetic is fp32) timed for `--steps` steps with nothing but the
+step itself inside the timed region, the per-kernel HIP-event times from a separate untimed pass right after it, plus
+`by_precision` with the other modes of `--also` timed in the same run (>= 20 steps each).
 """
 import argparse
 import json
@@ -42,7 +44,12 @@ B32 = {"fwd": 10 * 1024 + 256 + 128 + 320 + 16 + 8,
 B16 = {"fwd": 10 * 512 + 128 + 64 + 320 + 16 + 8,
        "bwd": 10 * 512 + 64 + 320 + 64 + 32 + 8,
        "dw": 2 * 512 * 8 + (2 * 512 + 128) + (512 + 128) + 2 * (512 + 64)}    # the skip layer reads [hidden | encoded] against its dY in one segment
-DTYPE_TEXT = {"f32": "f32", "f16x3": "f16x3 (split-f16 MFMA operands: 3 MFMAs per product, fp32 accumulate/storage)",
+#  f16x3 (hi + lo planes): 10 slots x 256 x 4 B (+ encoding 256, sh.2 outputs 128 fp32, masks 320, output 16, index 8);
+#  backward: d(sh.2) 128 written, sh.2 outputs 128 read; weight gradients: twice the 16-bit kernel's fragments
+BX3 = {"fwd": 10 * 1024 + 256 + 128 + 320 + 16 + 8,
+       "bwd": 10 * 1024 + 128 + 320 + 128 + 32 + 8,
+       "dw": 2 * (2 * 512 * 8 + (2 * 512 + 128) + (512 + 128) + 2 * (512 + 64))}
+DTYPE_TEXT = {"f32": "f32", "f16x3": "f16x3 (fp32-grade: every operand hi + lo f16 = 22 significand bits, 3 f16 MFMAs per product, fp32 accumulate / bias / epilogues, 4-byte saved operands)",
               "f16": "f16 (single-pass f16 MFMA operands, fp32 accumulate, 2-byte workspaces)",
               "bf16": "bf16 (single-pass bf16 MFMA operands, fp32 accumulate, 2-byte workspaces)"}
 RIG_NAMES = {"ball": "Ball_Lego", "array": "Array_Ficus", "halfball": "HalfBall_Materials", "room": "Room_Statue"}
@@ -67,9 +74,28 @@ def launch_ranks(args, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    # poll all ranks: a rank that dies (import error, out of memory) leaves the others blocked in the rendezvous or in
+    # the next collective until the RCCL timeout, so the first failure ends the run
+    deadline = time.time() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "3600"))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                if r != 0:
+                    rc = rc or (r if 0 < r < 256 else 1)
+        if rc or time.time() > deadline:
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return rc or 124
+        time.sleep(0.05)
     return rc
 
 
@@ -255,13 +281,18 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     for i in range(warmup):
         step(i, False)
     barrier()
-    timer.reset()
-    timer.enabled = True
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i in range(steps):                          # the timed region: nothing but the steps
         step(warmup + i, True)
     barrier()
     dt = time.perf_counter() - t0
+    # per-kernel launch durations (HIP events on the launch stream around the three fine / coarse MLP calls): a separate,
+    # untimed pass over the same workload
+    timer.reset()
+    timer.enabled = True
+    for i in range(min(5, steps)):
+        step(warmup + steps + i, False)
+    barrier()
     timer.enabled = False
     tmax = torch.tensor([dt], device=dev)
     if world > 1:
@@ -276,10 +307,12 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(torch.equal(lo, hi))
     finite = bool(all(torch.isfinite(p).all() for p in model.parameters()))
+    skipped = int(opt.skipped_steps())              # optimiser steps the overflow guard refused (inf / NaN gradients): must be 0
     k_mean = float(torch.stack(counts).float().mean())
     ks = timer.summary()
     rec = {"precision": precision, "value": args.rays * world * steps / dt, "unit": "rays/s", "steps": steps,
            "ms_per_step": dt / steps * 1e3, "fine_samples_per_ray": k_mean / args.rays, "finite": finite,
+           "skipped_optimizer_steps": skipped, "valid": bool(finite and skipped == 0),
            "kernel_ms": {f"mlp_{k}<{w}>": v for (k, w), v in sorted(ks.items())}}
     if world > 1:
         rec["allreduce_ms"] = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
@@ -287,7 +320,7 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
         rec["asymmetric_grad_steps"] = sync.asymmetric_steps()      # ranks disagreeing on which tensors have gradients: must be 0
     # roofline of the fine-net kernels with ALGORITHMIC work per launch over the HIP-event launch time
     mfma_peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
-    contract = B16 if precision in ("f16", "bf16") else B32
+    contract = B16 if precision in ("f16", "bf16") else (BX3 if precision == "f16x3" else B32)
     per_call = {}
     for k in ("fwd", "bwd", "dw"):
         ms = ks.get((k, 256))
@@ -304,24 +337,41 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     return rec, k_mean
 
 
+def csrc_digest():
+    """Content digest of the kernel sources (the GPU box has no .git): a recorded profile belongs to the kernels it names."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "mc_nerf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(precision, kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command
-    (scripts/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KB units, FETCH doubled on gfx950 as
-    MI355X_MICROARCH.md prescribes).  Pre-recorded, not measured in this run: returns (bytes | None, source)."""
-    cand = {"f16": "r02_pmc_traffic_f16.json", "bf16": "r02_pmc_traffic_bf16.json", "f16x3": "r01i_pmc_traffic.json", "f32": "r01c_pmc_traffic.json"}
-    path = os.path.join(ROOT, "profiles", cand.get(precision, ""))
+    (scripts/pmc_bench.sh -> scripts/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KB units, FETCH doubled on
+    gfx950 as MI355X_MICROARCH.md prescribes).  Pre-recorded, not measured in this run; dropped (None) when the kernel
+    sources have changed since the recording.  Returns (bytes | None, source text | None)."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{precision}.json")
     if not os.path.isfile(path):
         return None, None
     names = {"f16": {"mlp_fwd<256>": "mlp16_fwd_kernel<256, true, false>", "mlp_bwd<256>": "mlp16_bwd_kernel<256, false>",
                      "mlp_dw<256>": "dw16_stream_kernel<256, false>"},
              "bf16": {"mlp_fwd<256>": "mlp16_fwd_kernel<256, true, true>", "mlp_bwd<256>": "mlp16_bwd_kernel<256, true>",
                       "mlp_dw<256>": "dw16_stream_kernel<256, true>"},
-             "f16x3": {"mlp_fwd<256>": "mlp_fwd_h_kernel<256, true>", "mlp_bwd<256>": "mlp_bwd_h_kernel<256>"},
+             "f16x3": {"mlp_fwd<256>": "mlp_x3_fwd_kernel<256, true>", "mlp_bwd<256>": "mlp_x3_bwd_kernel<256>",
+                       "mlp_dw<256>": "dwx3_stream_kernel<256>"},
              "f32": {"mlp_fwd<256>": "mlp_fwd_kernel<256, true>", "mlp_bwd<256>": "mlp_bwd_kernel<256>"}}[precision]
-    kern = json.load(open(path)).get("kernels", {})
+    rec = json.load(open(path))
+    if rec.get("csrc_digest") != csrc_digest():
+        return None, f"profiles/{os.path.basename(path)} was recorded for other kernel sources (digest {rec.get('csrc_digest')}): not used"
     k = names.get(kernel_key)
+    kern = rec.get("kernels", {})
     if k in kern:
-        return kern[k]["hbm_bytes_per_launch"], f"pre-recorded rocprofv3 PMC passes: profiles/{os.path.basename(path)} (N = 32768)"
+        return kern[k]["hbm_bytes_per_launch"], (f"pre-recorded rocprofv3 PMC passes of this command: profiles/{os.path.basename(path)} "
+                                                  f"(N = 32768, kernel sources {rec.get('csrc_digest')})")
     return None, None
 
 
@@ -357,16 +407,15 @@ def run_rank(args):
     head, k_mean = run_precision(args.precision, args, args.steps, args.warmup, rank, world, dev, timer, cache)
     others = {}
     for p in [q for q in args.also.split(",") if q and q != args.precision]:
-        s = max(5, args.steps // (10 if p == "f32" else 5))
-        others[p], _ = run_precision(p, args, s, 2, rank, world, dev, timer, cache)
+        others[p], _ = run_precision(p, args, max(20, args.steps // 5), 3, rank, world, dev, timer, cache)
     if rank == 0:
         pc = head["per_call"]
-        # The dominant KERNEL is the longest single launch.  In the 16-bit modes every fine-net call is one launch and the
-        # weight-gradient kernel is the longest; in f32 / f16x3 mlp_dw is 15 launches per call (aggregate in `per_call`) and
-        # the longest launch is a chain.  SURVEY 8(d) names the bound of this path as MFMA: `frac` is the MFMA fraction of
+        # The dominant KERNEL is the longest single launch.  In the register-chain modes (f16x3, f16, bf16) every fine-net call
+        # is one launch and the weight-gradient kernel is the longest; in f32 mlp_dw is 15 launches per call (aggregate in
+        # `per_call`) and the longest launch is a chain.  SURVEY 8(d) names the bound of this path as MFMA: `frac` is the MFMA fraction of
         # that kernel; the HBM roof (contract bytes and measured PMC bytes) sits beside it in `other_roof` -- for the
         # weight-gradient kernel THAT is the roof that binds (it streams its GEMM operands once: `binding_roof`).
-        single = pc if args.precision in ("f16", "bf16") else {k: v for k, v in pc.items() if k != "mlp_dw<256>"}
+        single = pc if args.precision != "f32" else {k: v for k, v in pc.items() if k != "mlp_dw<256>"}
         dom = max(single, key=lambda k: single[k]["ms"])
         mfma_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
         traffic, tsrc = pmc_traffic(args.precision, dom) if args.rays == 32768 else (None, None)
@@ -390,13 +439,19 @@ def run_rank(args):
             "roofline": roof,
             "by_precision": {p: {k: v for k, v in r.items() if k != "precision"} for p, r in others.items()},
         }
-        for k in ("allreduce_ms", "params_identical_across_ranks", "asymmetric_grad_steps", "finite"):
+        for k in ("allreduce_ms", "params_identical_across_ranks", "asymmetric_grad_steps", "finite", "skipped_optimizer_steps", "valid"):
             if k in head:
                 out[k] = head[k]
         if world == 1 and not args.no_cpu_baseline:
             out["parity"] = parity_probe(args.precision, dev)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
+        bad = [p for p, r in [(args.precision, head)] + list(others.items()) if not r["valid"]]
+        if bad:                 # a mode whose steps were skipped by the overflow guard (or went non-finite) measured nothing
+            print(f"bench.py: INVALID measurement in mode(s) {bad}: non-finite parameters or optimiser steps skipped", file=sys.stderr)
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(3)
     if world > 1:
         dist.destroy_process_group()
 
@@ -449,7 +504,7 @@ def run_render(args, rank, world, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=32768, help="rays per step per GPU (config `batch`)")
     ap.add_argument("--samples", type=int, default=64, help="coarse samples per ray (config `samples`; reference default 128)")
@@ -457,10 +512,10 @@ def main():
     ap.add_argument("--img", type=int, default=800, help="image side (BASELINE cfg 5: 1600)")
     ap.add_argument("--rig", default="ball", choices=["ball", "array", "halfball", "room"], help="camera rig of the synthetic scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f16", choices=["f32", "f16x3", "f16", "bf16"],
-                    help="MFMA mode of the MLP kernels: single-pass f16 / bf16 (throughput modes), split-f16 f16x3 or exact f32 "
-                         "(the 1e-4 parity modes)")
-    ap.add_argument("--also", default="f16x3,bf16,f32", help="other precision modes measured in the same run (by_precision)")
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16", "bf16", "f16x3r1"],
+                    help="MFMA mode of the MLP kernels: split-f16 f16x3 (fp32-grade, the headline: the reference computes in fp32) or "
+                         "exact f32 -- the 1e-4 parity modes; single-pass f16 / bf16 -- 16-bit operand modes with their own stated error")
+    ap.add_argument("--also", default="f16,bf16,f32", help="other precision modes measured in the same run (by_precision)")
     ap.add_argument("--mode", default="train", choices=["train", "render"])
     ap.add_argument("--selftest", action="store_true", help="rendezvous / launcher check only (no kernels; works on CPU)")
     args = ap.parse_args()

@@ -260,13 +260,16 @@ int mcnerf_scale3(float* a, int na, float* b, int nb, float* c, int nc, const fl
  * Replaces the per-tensor loop of RAdam.step (model/net_utils.py:38-99).  The arrays of n_tensors device
  * pointers / sizes live on the HOST; step_size and `rectified` (N_sma >= 5) are the host-side scalars of the
  * reference's step-size cache (model/net_utils.py:67-86) for the tensors' common step count.
- * guard (device uint32[2], or NULL): overflow guard of the reduced-precision modes -- guard[0] is raised when any gradient
- * of the call is inf / NaN, the whole call then leaves parameters and moments untouched and guard[1] counts the skipped
- * step (the caller zero-initialises guard[1] once and reads it whenever it likes; no synchronisation here).  Note: a call
- * of more than 64 tensors is split into launches of 64; the check covers each launch's tensors before its update. */
+ * guard (device uint32[2], or NULL): overflow guard of the reduced-precision modes -- guard[0] is raised when a gradient is
+ * inf / NaN, an update then leaves parameters and moments untouched, and guard[1] counts refused steps (the caller
+ * zero-initialises guard[1] once and reads it whenever it likes; no synchronisation here).
+ * phase (bit set) lets ONE optimiser step that spans several calls (param groups, step counts) be refused as a whole:
+ *   1 = clear guard[0] first, 2 = check this call's gradients, 4 = update this call's tensors, 8 = this call is the step's
+ *   last update: count a refused step in guard[1].  A self-contained step is phase 15; a multi-call step runs (1|2), 2, ...
+ *   over all its calls and then 4, ..., (4|8).  Within a call every check precedes every update. */
 int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const long long* sizes, float lr, float beta1, float beta2, float eps,
-                      float weight_decay, float step_size, int rectified, uint32_t* guard, void* stream);
+                      float weight_decay, float step_size, int rectified, uint32_t* guard, int phase, void* stream);
 
 #ifdef __cplusplus
 }

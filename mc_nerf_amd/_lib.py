@@ -65,7 +65,7 @@ SIGNATURES = {
     "mcnerf_camera_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mcnerf_reproj_loss_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "mcnerf_reproj_loss_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
-    "mcnerf_radam_step": (_I, [_I, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_float, _I, _P, _P]),
+    "mcnerf_radam_step": (_I, [_I, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_float, _I, _P, _I, _P]),
 }
 
 _lib = None

@@ -380,23 +380,42 @@ int mcnerf_reproj_loss_bwd(const float* pd, const float* gt, int n, int H, int W
 
 int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const long long* sizes, float lr, float beta1, float beta2, float eps,
-                      float weight_decay, float step_size, int rectified, uint32_t* guard, void* stream) {
-    REQ(n_tensors >= 0 && params && grads && exp_avg && exp_avg_sq && sizes, "mcnerf_radam_step");
-    for (int t0 = 0; t0 < n_tensors; t0 += MCN_RADAM_MAXT) {           // 64 tensors per launch
+                      float weight_decay, float step_size, int rectified, uint32_t* guard, int phase, void* stream) {
+    REQ(n_tensors >= 0 && params && grads && exp_avg && exp_avg_sq && sizes && (phase & ~15) == 0, "mcnerf_radam_step");
+    for (int i = 0; i < n_tensors; ++i)
+        REQ(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i] && sizes[i] >= 0, "mcnerf_radam_step");
+    auto table = [&](int t0, int& blocks) {                           // 64 tensors per launch
         McnRadamTable t;
         t.n_tensors = n_tensors - t0 < MCN_RADAM_MAXT ? n_tensors - t0 : MCN_RADAM_MAXT;
         t.rectified = rectified; t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.wd = weight_decay;
         t.step_size = step_size;
-        int blocks = 0;
+        blocks = 0;
         for (int i = 0; i < t.n_tensors; ++i) {
-            REQ(params[t0 + i] && grads[t0 + i] && exp_avg[t0 + i] && exp_avg_sq[t0 + i] && sizes[t0 + i] >= 0, "mcnerf_radam_step");
             t.p[i] = params[t0 + i]; t.g[i] = grads[t0 + i]; t.m[i] = exp_avg[t0 + i]; t.v[i] = exp_avg_sq[t0 + i];
             t.n[i] = sizes[t0 + i];
             t.first_block[i] = blocks;
             blocks += (int)((sizes[t0 + i] + MCN_RADAM_CHUNK - 1) / MCN_RADAM_CHUNK);
         }
-        const int rc = check("mcnerf_radam_step", mcn_launch_radam(t, blocks, guard, t0 == 0, (hipStream_t)stream));
+        return t;
+    };
+    McnRadamTable none;
+    none.n_tensors = 0;
+    if (guard && (phase & 1)) {
+        const int rc = check("mcnerf_radam_step", mcn_launch_radam(none, 0, guard, 1, (hipStream_t)stream));
         if (rc) return rc;
+    }
+    // every check of the call precedes every update: a non-finite gradient in a later chunk of 64 tensors must not find the
+    // earlier chunks already updated
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 0 ? !(guard && (phase & 2)) : !(phase & 4)) continue;
+        for (int t0 = 0; t0 < n_tensors; t0 += MCN_RADAM_MAXT) {
+            int blocks;
+            const McnRadamTable t = table(t0, blocks);
+            const bool last = t0 + MCN_RADAM_MAXT >= n_tensors;
+            const int ph = pass == 0 ? 2 : (4 | (last ? (phase & 8) : 0));
+            const int rc = check("mcnerf_radam_step", mcn_launch_radam(t, blocks, guard, ph, (hipStream_t)stream));
+            if (rc) return rc;
+        }
     }
     return 0;
 }

@@ -162,7 +162,7 @@ struct McnRadamTable {
     long long n[MCN_RADAM_MAXT];
     int first_block[MCN_RADAM_MAXT];
 };
-hipError_t mcn_launch_radam(const McnRadamTable& t, int n_blocks, unsigned* guard, bool first_of_group, hipStream_t st);
+hipError_t mcn_launch_radam(const McnRadamTable& t, int n_blocks, unsigned* guard, int phase, hipStream_t st);
 
 // ---- fused camera parametrisation (camera.hip)
 struct McnCameraArgs {

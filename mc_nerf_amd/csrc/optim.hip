@@ -27,9 +27,9 @@ __global__ __launch_bounds__(256) void radam_check_kernel(McnRadamTable t, unsig
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(guard, 1u);
 }
 
-__global__ __launch_bounds__(256) void radam_kernel(McnRadamTable t, unsigned* guard) {
+__global__ __launch_bounds__(256) void radam_kernel(McnRadamTable t, unsigned* guard, int count_skip) {
     if (guard && guard[0]) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&guard[1], 1u);
+        if (count_skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&guard[1], 1u);
         return;
     }
     // block -> (tensor, chunk): blocks are dealt to tensors by their precomputed first-block index
@@ -59,15 +59,14 @@ __global__ __launch_bounds__(256) void radam_kernel(McnRadamTable t, unsigned* g
     }
 }
 
-hipError_t mcn_launch_radam(const McnRadamTable& t, int n_blocks, unsigned* guard, bool first_of_group, hipStream_t st) {
-    if (n_blocks <= 0) return hipSuccess;
-    if (guard) {
-        if (first_of_group) {
-            hipError_t e = hipMemsetAsync(guard, 0, sizeof(unsigned), st);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(radam_check_kernel, dim3(n_blocks), dim3(256), 0, st, t, guard);
+// phase bits (include/mcnerf.h): 1 = clear guard[0] first, 2 = check the gradients, 4 = update, 8 = this launch counts a refused step
+hipError_t mcn_launch_radam(const McnRadamTable& t, int n_blocks, unsigned* guard, int phase, hipStream_t st) {
+    if (guard && (phase & 1)) {
+        hipError_t e = hipMemsetAsync(guard, 0, sizeof(unsigned), st);
+        if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(radam_kernel, dim3(n_blocks), dim3(256), 0, st, t, guard);
+    if (n_blocks <= 0) return hipSuccess;
+    if (guard && (phase & 2)) hipLaunchKernelGGL(radam_check_kernel, dim3(n_blocks), dim3(256), 0, st, t, guard);
+    if (phase & 4) hipLaunchKernelGGL(radam_kernel, dim3(n_blocks), dim3(256), 0, st, t, guard, (phase & 8) ? 1 : 0);
     return hipGetLastError();
 }

@@ -85,6 +85,7 @@ class FlatGradSync:
         self._flag_cache = {}                      # tuple of local flags -> device tensor (no per-step host -> device copy)
         self._trusted = set()                      # local flag patterns verified to be the same on every rank
         self._asym = torch.zeros((), dtype=torch.int32, device=dev)
+        self._stage = None                         # the model's stage (opt_idx) of the last sync: trust does not survive a stage change
 
     def broadcast_parameters(self):
         """Rank 0's parameters to everyone (what the DDP constructor does, main.py:61)."""
@@ -134,6 +135,10 @@ class FlatGradSync:
             have.append(1.0 if p.grad is not None else 0.0)
             o += sz
         key = tuple(have)
+        stage = getattr(self.model, "opt_idx", None)
+        if stage != self._stage:                   # a new stage (main.py:79 switches optimisers on it): every rank re-verifies its
+            self._stage = stage                    # pattern on the stage's first step, so no rank keeps trusting across a boundary
+            self._trusted.clear()                  # where another rank's pattern changed
         local = self._flag_cache.get(key)
         if local is None:                          # (first step of a stage only)
             local = self._flag_cache[key] = torch.tensor(have, dtype=torch.float32, device=self.arena.device)

@@ -41,6 +41,7 @@ class RAdam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        buckets = []            # (tensors, group, n_sma, step_size): the fused launches of this step
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             fused = {}          # step count -> tensors updated by one fused launch
@@ -63,7 +64,19 @@ class RAdam(Optimizer):
                     self._step_host(p, p.grad, st, group, slot[1], slot[2])
             for step, ps in fused.items():
                 slot = group["buffer"][step % 10]
-                self._step_fused(ps, group, slot[1], slot[2])
+                buckets.append((ps, group, slot[1], slot[2]))
+        # the overflow guard covers the WHOLE step: every bucket's gradients are checked before any bucket is updated, so a
+        # non-finite gradient anywhere refuses the step everywhere (counted once).  (The host-side step counters have
+        # advanced by then: after a refused step the bias corrections run one step ahead -- a refused step is an error
+        # condition, see raise_on_overflow, not a mode of operation.)
+        first, last = {}, {}    # (one guard per device)
+        for i, b in enumerate(buckets):
+            first.setdefault(b[0][0].device, i)
+            last[b[0][0].device] = i
+        for i, (ps, group, n_sma, ss) in enumerate(buckets):
+            self._step_fused(ps, group, n_sma, ss, phase=(1 if first[ps[0].device] == i else 0) | 2)
+        for i, (ps, group, n_sma, ss) in enumerate(buckets):
+            self._step_fused(ps, group, n_sma, ss, phase=4 | (8 if last[ps[0].device] == i else 0))
         return loss
 
     def skipped_steps(self) -> int:
@@ -93,7 +106,7 @@ class RAdam(Optimizer):
                 p.add_(p, alpha=-wd * lr)
             p.add_(m, alpha=-step_size * lr)
 
-    def _step_fused(self, ps, group, n_sma, step_size):
+    def _step_fused(self, ps, group, n_sma, step_size, phase=15):
         n = len(ps)
         PtrArr, SizeArr = ctypes.c_void_p * n, ctypes.c_longlong * n
         grads = []
@@ -115,4 +128,4 @@ class RAdam(Optimizer):
         with torch.cuda.device(dev):
             _lib.call("mcnerf_radam_step", n, *[ctypes.cast(a, ctypes.c_void_p) for a in args],
                       float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]),
-                      float(step_size), int(n_sma >= 5), self._guard[dev].data_ptr(), torch.cuda.current_stream().cuda_stream)
+                      float(step_size), int(n_sma >= 5), self._guard[dev].data_ptr(), int(phase), torch.cuda.current_stream().cuda_stream)

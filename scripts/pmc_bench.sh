@@ -9,4 +9,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p gpurun_out/pmc_${TAG}_${PREC}_$c
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_${PREC}_$c -- $CMD > gpurun_out/pmc_${TAG}_${PREC}_$c/log.txt 2>&1
 done
-python3 scripts/pmc_traffic.py gpurun_out/pmc_${TAG}_${PREC}_FETCH_SIZE gpurun_out/pmc_${TAG}_${PREC}_WRITE_SIZE gpurun_out/${TAG}_pmc_traffic_${PREC}.json "$CMD"
+python3 scripts/pmc_traffic.py gpurun_out/pmc_${TAG}_${PREC}_FETCH_SIZE gpurun_out/pmc_${TAG}_${PREC}_WRITE_SIZE gpurun_out/pmc_traffic_${PREC}.json "$CMD"

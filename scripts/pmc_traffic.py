@@ -6,8 +6,9 @@ into profiles/<tag>_pmc_traffic.json: mean HBM bytes per launch and kernel.
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md: counter unit is KB; FETCH_SIZE is doubled on gfx950 (a wide
 coalesced read is reported at half its size); WRITE_SIZE is taken as is.
 """
-import csv, glob, json, re, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(d, counter):
@@ -37,6 +38,7 @@ def main():
     json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (each with --kernel-trace only), "
                          f"command: {cmd}; counter unit KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a "
                          "wide coalesced read), WRITE_SIZE taken as is; mean over dispatches",
+               "csrc_digest": __import__("bench").csrc_digest(),
                "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
         print(f"{k:40s} {v['hbm_bytes_per_launch'] / 1e9:9.3f} GB/launch (fetch {v['fetch_bytes_corrected'] / 1e9:.3f}, write {v['write_bytes'] / 1e9:.3f})")

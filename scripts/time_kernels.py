@@ -34,8 +34,12 @@ fns = {
 # 100 MHz counter every 50 us while the timed kernel runs -> effective MHz under that kernel's load
 probe = None
 if os.environ.get("CLOCKPROBE"):
-    import ctypes
-    probe = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "dbg", "libclockprobe.so"))
+    import ctypes, subprocess
+    _dbg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dbg")
+    if not os.path.exists(os.path.join(_dbg, "libclockprobe.so")):      # debug-only probe: built on demand, not by __graft_entry__.build()
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O2", "-shared", "-fPIC",
+                        "-o", os.path.join(_dbg, "libclockprobe.so"), os.path.join(_dbg, "clockprobe.hip")], check=True)
+    probe = ctypes.CDLL(os.path.join(_dbg, "libclockprobe.so"))
     probe.clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]
     side = torch.cuda.Stream()
 res = []
