@@ -264,8 +264,10 @@ def g9_cameras():
 
 
 # ----------------------------------------------------------------------------- G11: full MC_Model step
-def g11_mc_model_step():
-    """MC_Model.forward in the GLOBAL_OPTIM stage + MC_NeRF_Loss + backward, from the actual reference."""
+def g11_mc_model_step(stage="GLOBAL_OPTIM_EPOCH", tag="g11_mc_model_step", extr_shift=0.0):
+    """MC_Model.forward in one of the three stages (model/mc_nerf.py:64-71 CAM_PARAM, :73-83 GLOBAL_OPTIM, :85-95
+    FINE_TUNE) + MC_NeRF_Loss + backward, from the actual reference.  `extr_shift` offsets the extrinsic calibration
+    pixels so that the CAM_PARAM stage's two reprojection branches see different targets."""
     from mc_nerf_amd import synthetic as S
     H, W, B, cam = 24, 32, 96, 7
     sp = S.make_sys_param("cpu", samples=32, scale=2, batch=B, H=H, W=W, coarse=(4, 32, [2]), fine=(8, 64, [4]),
@@ -275,24 +277,31 @@ def g11_mc_model_step():
     S.init_cameras_near_gt(model, noise=0.02, seed=1)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0], seed=2)
+    wpts_e, pts_e = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0], seed=4)
+    pts_e = pts_e + extr_shift
     g = torch.Generator().manual_seed(11)
     gt_img = torch.rand(1, H * W, 3, generator=g)
-    data = (gt_img, torch.tensor([cam]), wpts, pts, wpts, pts)
+    data = (gt_img, torch.tensor([cam]), wpts, pts, wpts_e, pts_e)
     with Capture() as c:
         torch.manual_seed(5)
-        loss_dict, intr_show, pose_show, rays_valid = model(data, 20, "GLOBAL_OPTIM_EPOCH", 0.6)
-    loss = MC_NeRF_Loss(sp)(loss_dict, "GLOBAL_OPTIM_EPOCH")
+        loss_dict, intr_show, pose_show, rays_valid = model(data, 20, stage, 0.6)
+    loss = MC_NeRF_Loss(sp)(loss_dict, stage)
     loss.backward()
     rn = c.of("randn")
     arrs = dict(H=H, W=W, B=B, cam=cam, cur_ratio=0.6, barf=np.array([0.2, 0.9]), gt_img=gt_img, wpts=wpts, pts=pts,
-                rand_idx=c.of("randperm")[0][:B], jitter=c.of("uniform")[0], eps_c=rn[0], eps_sel=rn[1], eps_f=rn[2],
-                loss=loss, rgb_c=loss_dict["rgb"][0], rgb_f=loss_dict["rgb"][1], reproj=loss_dict["intr"][0],
+                wpts_e=wpts_e, pts_e=pts_e, opt_idx=model.opt_idx,
+                loss=loss, reproj=loss_dict["intr"][0],
                 K=intr_show[1], pose=pose_show[1], rays_valid_d=rays_valid[0][::37], rays_valid_o=rays_valid[1][:1])
+    if "extr" in loss_dict:
+        arrs["reproj_extr"] = loss_dict["extr"][0]
+    if "rgb" in loss_dict:
+        arrs.update(rand_idx=c.of("randperm")[0][:B], jitter=c.of("uniform")[0], eps_c=rn[0], eps_sel=rn[1], eps_f=rn[2],
+                    rgb_c=loss_dict["rgb"][0], rgb_f=loss_dict["rgb"][1])
     for k, v in state.items():
         arrs["p." + k] = v
     for k, p in model.named_parameters():
         arrs["g." + k] = p.grad if p.grad is not None else np.zeros(0, np.float32)
-    npz("g11_mc_model_step", **arrs)
+    npz(tag, **arrs)
 
 
 # ----------------------------------------------------------------------------- G12: RAdam + loss
@@ -330,6 +339,8 @@ def g12_radam():
 def main():
     torch.set_num_threads(4)
     g11_mc_model_step()
+    g11_mc_model_step("CAM_PARAM_EPOCH", "g11b_mc_model_cam_param", extr_shift=0.7)
+    g11_mc_model_step("FINE_TUNE_EPOCH", "g11c_mc_model_fine_tune")
     g12_radam()
     g1_embed()
     g3_mlp()
