@@ -298,11 +298,12 @@ def test_mlp16_dw_at_scale(gpu_device, width, precision):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # The 16-bit modes against the REFERENCE's golden renders (tests/golden, generated from /root/reference by
-# tests/golden/make_golden.py): measured error of rgb / depth and relative L2 of the gradients.  Stated tolerance of the
-# mode on these fixtures: rgb, opacity 2e-3 (f16) / 2e-2 (bf16) abs; depth (values up to 8) 1e-2 / 1e-1 abs; a ray whose
-# coarse weights sit within the operand rounding of the selection threshold can gain or lose a fine sample (the
-# reference's selection is discontinuous, SURVEY.md 7 "hard parts"), which these bounds include.
-TOL_GOLDEN = {"f16": (2e-3, 1e-2, 0.12), "bf16": (2e-2, 1e-1, 0.4)}      # (rgb / opacity, depth, gradient relative L2)
+# tests/golden/make_golden.py).  Stated accuracy of the modes on these fixtures = about 3x what they measure on MI355X:
+#   f16 : rgb / opacity <= 1.2e-5, depth <= 6.0e-6, gradients <= 4.0e-2 relative L2 (worst of the 40 tensors and of the ray gradients)
+#   bf16: rgb / opacity <= 1.2e-4, depth <= 3.5e-5, gradients <= 9.6e-2
+# (the fixtures are 48-96 rays on 32- / 64-wide nets, so a single ReLU decision that falls the other way under the operand
+# rounding is visible in a gradient tensor; at the bench size the whole-gradient error is 2e-3 / 6e-3, test_full_size_16bit_modes_against_f32).
+TOL_GOLDEN = {"f16": (5e-5, 5e-5, 0.08), "bf16": (4e-4, 2e-4, 0.2)}      # (rgb / opacity, depth, gradient relative L2)
 
 
 def _golden_model(g, dev, precision):
