@@ -347,6 +347,89 @@ def test_valid_train_renders_the_checkpoint_just_saved(gpu_device, tmp_path, pre
     assert float(val["psnr"]) > 0.0 and os.path.exists(os.path.join(model.nerf.train_img_pth, model.nerf.data_name, "epoch_3.png"))
 
 
+RIG_CASES = [("array", 800, 64, 2, "f16x3"), ("halfball", 800, 64, 2, "f16x3"), ("room", 800, 64, 2, "f16x3"),     # BASELINE cfg 3, cfg 4, (cfg 5's rig)
+             ("room", 1600, 64, 4, "bf16"), ("array", 1600, 64, 4, "bf16")]                                           # cfg 5: 1600 x 1600, fine grid 256, bf16
+
+
+@pytest.mark.parametrize("rig,H,samples,scale,precision", RIG_CASES)
+def test_rig_configs_one_global_optim_step(gpu_device, rig, H, samples, scale, precision):
+    """BASELINE.json configs[2..4] at their geometry: the Array (C = 100, synthetic_dataset_code/Array.py:176-191), HalfBall
+    (C = 100, HalfBall.py:162-178) and Room (C = 88, Room.py:171-180) rigs, 800 x 800 with 64 x 2 sampling in the fp32-grade
+    mode and 1600 x 1600 (2.56 M pixel ids through sample_perm / raygen / gather_gt) with 64 x 4 sampling in bf16, where the
+    random cap of model/mc_nerf.py:630-632 binds.  One GLOBAL_OPTIM step of MC_Model at N = 4096 rays with full-size nets
+    (the model draws its own pixel subset on the device); a 128-ray subset (same pixel ids, same draws) goes through the CPU
+    oracle: rays, ground truth, coarse render -- and the fine render where the cap does not interfere."""
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd.data import DeviceImageSet
+    from mc_nerf_amd.model import MC_Model, MC_NeRF_Loss
+    dev = gpu_device
+    W, N, n_sub = H, 4096, 128
+    Sf = samples * scale
+    sp = S.make_sys_param(dev, samples=samples, scale=scale, batch=N, H=H, W=W, barf_mask=False, precision=precision, rig=rig)
+    torch.manual_seed(21)
+    model = MC_Model(sp).to(dev)
+    S.init_cameras_near_gt(model, noise=1e-3)
+    C = model.train_numb
+    assert C == {"array": 100, "halfball": 100, "room": 88}[rig]
+    cam = C - 3
+    images = DeviceImageSet.synthetic(C, H, W, dev, channels=4, seed=7)
+    wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0], seed=2)
+    gd = torch.Generator(device=dev).manual_seed(5)
+    draws = dict(jitter=torch.rand(N, 1, device=dev, generator=gd) * 7.0 / samples, eps_c=torch.randn(N, samples, device=dev, generator=gd),
+                 eps_sel=torch.randn(N, samples, device=dev, generator=gd), eps_f=torch.randn(N, Sf, device=dev, generator=gd))
+    seen = {}
+    orig_pix = model.sample_pixels
+
+    def pix_and_record(npix):
+        seen["pix"] = orig_pix(npix)
+        return seen["pix"]
+    model.sample_pixels = pix_and_record
+    orig = model.nerf.render_rays_train
+    model.nerf.render_rays_train = lambda d, o, e, r, only_coarse=False: orig(d, o, e, r, only_coarse, **draws)
+    loss_dict, _, _, _ = model((images, torch.tensor([cam]), wpts.to(dev), pts.to(dev), wpts.to(dev), pts.to(dev)), 20, "GLOBAL_OPTIM_EPOCH", 0.6)
+    loss = MC_NeRF_Loss(sp)(loss_dict, "GLOBAL_OPTIM_EPOCH")
+    loss.backward()
+    pix = seen["pix"].cpu()
+    assert pix.shape == (N,) and int(pix.min()) >= 0 and int(pix.max()) < H * W and pix.unique().numel() == N
+    k = int(model.nerf.last_selection[1].item())
+    capped = Sf > 128
+    if capped:
+        assert k == N * 128, (k, N * 128)                  # the cap binds (random-init weights select ~3/4 of the fine grid)
+    else:
+        assert 0 < k <= N * Sf
+    rgb_c, rgb_f, gt = (x.detach().cpu() for x in loss_dict["rgb"])
+    assert torch.isfinite(rgb_c).all() and torch.isfinite(rgb_f).all() and float(rgb_f.min()) >= 0.0 and float(rgb_f.max()) <= 1.0 + 1e-6
+    for n_, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n_
+    assert float(model.weights_pose.grad[cam].abs().max()) > 0.0
+    # ---- the subset through the oracle
+    sub = torch.randperm(N, generator=torch.Generator().manual_seed(9))[:n_sub]
+    cp = {n_: p.detach().cpu() for n_, p in model.named_parameters()}
+    pc = {k_[len("nerf.nerf_coarse."):]: v for k_, v in cp.items() if k_.startswith("nerf.nerf_coarse.")}
+    pf = {k_[len("nerf.nerf_fine."):]: v for k_, v in cp.items() if k_.startswith("nerf.nerf_fine.")}
+    Kc = O.intrinsics_from_weights(H, W, cp["weights_fx"], cp["weights_fy"], cp["weights_ux"], cp["weights_uy"])
+    pose = O.se3_to_SE3(cp["weights_pose"])
+    d_ref, o_ref = O.get_rays_at(pose[cam], torch.linalg.inv(Kc[cam]), pix[sub], W)
+    u8 = images.images[cam].cpu()[pix[sub]].float() / 255.0                       # RGBA on white (data/data_read.py:130-137)
+    gt_ref = u8[:, :3] * u8[:, 3:] + (1.0 - u8[:, 3:])
+    assert float((gt[sub] - gt_ref).abs().max()) < 1e-6
+    cfg = O.RenderCfg(samples=samples, scale=scale, barf_mode=True, barf_start=sp["barf_start"], barf_end=sp["barf_end"])
+    dr = {k_: v.cpu()[sub] for k_, v in draws.items()}
+    with torch.no_grad():
+        r = O.render_rays_train(pc, pf, cfg, d_ref, o_ref, 0.6, dr["jitter"], dr["eps_c"], dr["eps_sel"], dr["eps_f"],
+                                cap_perm=torch.arange(n_sub * Sf) if capped else None)     # (any subset: only rgb_c is compared when the cap binds)
+    tol = {"f16x3": 1e-4, "bf16": 4e-4}[precision]
+    ec = float((rgb_c[sub] - r["rgb_c"]).abs().max())
+    msg = f"[{rig} {H}x{W} {samples}x{scale} {precision}] C = {C}, {k} fine samples, subset of {n_sub}: max|rgb_c - oracle| {ec:.1e}"
+    assert ec < tol, msg
+    if not capped:
+        ef = float((rgb_f[sub] - r["rgb_f"]).abs().max())
+        msg += f", max|rgb_f - oracle| {ef:.1e}"
+        assert ef < tol, msg
+    print(msg)
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f16"])
 def test_full_size_batch_subset_against_oracle(gpu_device, precision):
     """BASELINE cfg 2 at its size: 32768 rays through the coarse 4x128 + fine 8x256 train render; rendering is per-ray
