@@ -61,7 +61,7 @@ class FlatGradSync:
     size = DDP's averaging) and the parameters' `.grad` are pointed at / refreshed from it.
     """
 
-    def __init__(self, model, world: int, check_flags: bool = False):
+    def __init__(self, model, world: int, check_flags: bool = False, force_collective: bool = False):
         """A parameter receives the reduced gradient whenever ANY rank produced one (DDP semantics).  Deciding that needs the
         reduced "some rank has a gradient" flags on the host.  `check_flags=True` reads them back every step (one device ->
         host synchronisation per step).  The default reads them back only the FIRST time a local flag pattern occurs (a
@@ -69,6 +69,7 @@ class FlatGradSync:
         from then on and the step runs without host synchronisation, disagreement switches this object to `check_flags`
         for good; later disagreement under a trusted pattern is still counted on the device (`asymmetric_steps()`)."""
         self.model, self.world, self.check_flags = model, world, check_flags
+        self.force_collective = force_collective   # run the all-reduce even with one rank (exercises the backend on a 1-GPU box)
         nerf = model.nerf
         self.nets = [nerf.nerf_coarse, nerf.nerf_fine]
         for n in self.nets:
@@ -113,7 +114,7 @@ class FlatGradSync:
         """Call once after the step's single backward()."""
         nerf = self.model.nerf
         used = getattr(nerf, "grad_arena_used", False)
-        if self.world <= 1:                        # nothing to reduce: the gradients stay where backward() put them
+        if self.world <= 1 and not self.force_collective:      # nothing to reduce: the gradients stay where backward() put them
             nerf.grad_arena = None
             nerf.grad_arena_used = False
             return

@@ -139,8 +139,13 @@ class NeRF_Model(nn.Module):
                            self._dev(eps_c).contiguous(), self._dev(eps_sel).contiguous(), self._dev(eps_f).contiguous(), _prepared)
 
     # ------------------------------------------------------------------ per-pass API of the reference (:682-736)
-    @torch.no_grad()
     def inference(self, model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render=None, coarse=True, *, eps=None):
+        from .net_block import refuse_autograd
+        refuse_autograd("NeRF_Model.inference", [xyz, rays_d, z_vals, *model.parameters()])      # forward-only (docstring below)
+        with torch.no_grad():
+            return self._inference(model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render, coarse, eps=eps)
+
+    def _inference(self, model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render=None, coarse=True, *, eps=None):
         """One pass of one net on given samples -> (rgb [N,3], sigmas [N,S], xyz, depth [N,1], opacity [N,1]), the
         reference's `inference` (:682-727) for callers that use it directly.
 

@@ -16,7 +16,18 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops
+
+
+def refuse_autograd(what, tensors):
+    """The stand-alone per-module forwards run HIP kernels that have no backward of their own (the differentiable path is
+    NeRF_Model.render_rays_train / MC_Model.forward, one fused autograd.Function).  A caller that would differentiate
+    through them (model/net_block.py:20-35, 67-78 are differentiable in the reference) gets an error, not a tensor
+    without a graph."""
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        raise _lib.McnerfError(f"{what} is forward-only on the HIP path and was called with autograd recording on tensors that "
+                               "require a gradient: wrap the call in torch.no_grad(), or train through NeRF_Model.render_rays_train / "
+                               "MC_Model.forward (the fused differentiable render)")
 
 
 class SinCosEmbedding(nn.Module):
@@ -56,10 +67,15 @@ class SinCosEmbedding(nn.Module):
         w = self.barf_weights(step_r)
         return ops.upload_f32(w, device) if torch.device(device).type == "cuda" else w.to(device)
 
-    @torch.no_grad()
     def forward(self, x, step_r):
-        """Reference :20-35: [..., 3] -> [..., 63].  Stand-alone, forward-only call of the HIP encoding kernel (the render
-        path computes the encoding inside the fused MLP kernels and differentiates it there)."""
+        """Reference :20-35: [..., 3] -> [..., 63].  Stand-alone, FORWARD-ONLY call of the HIP encoding kernel (the render
+        path computes the encoding inside the fused MLP kernels and differentiates it there): asked for a gradient it
+        raises instead of returning a silently detached tensor."""
+        refuse_autograd("SinCosEmbedding.forward", [x])
+        with torch.no_grad():
+            return self._forward(x, step_r)
+
+    def _forward(self, x, step_r):
         flat = x.reshape(-1, 3).float().contiguous()
         out = ops.encode(flat, self.barf_weights_on(step_r, flat.device))
         return out.reshape(*x.shape[:-1], self.out_channels)
@@ -131,11 +147,17 @@ class CorseFine_NeRF(nn.Module):
         return [flat_grad[off:off + p.numel()].view(p.shape)
                 for p, off in zip(self.ordered_parameters(), self._offsets)]
 
-    @torch.no_grad()
     def forward(self, x, dirs):
         """Reference :67-78: encoded positions x [M,63] and view directions dirs [M,3] -> [M,4] = (sigma_raw, rgb).
-        Stand-alone, forward-only call of the exact-fp32 fused kernel on caller-supplied encodings (training
-        differentiates through the fused NeRF_Model.render_rays_train)."""
+        Stand-alone, FORWARD-ONLY call of the exact-fp32 fused kernel on caller-supplied encodings (training
+        differentiates through the fused NeRF_Model.render_rays_train): with autograd recording and a parameter or input
+        that requires a gradient it raises (wrap the call in torch.no_grad() for inference) instead of silently returning a
+        detached tensor that would train nothing."""
+        refuse_autograd("CorseFine_NeRF.forward", [x, dirs, *self.parameters()])
+        with torch.no_grad():
+            return self._forward(x, dirs)
+
+    def _forward(self, x, dirs):
         flat = self.flat_params()
         packed = ops.pack_weights(self.net, flat, precision="f32")
         return ops.mlp_apply(self.net, flat, packed, x.float().contiguous(), dirs.float().contiguous())

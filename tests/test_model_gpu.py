@@ -550,6 +550,64 @@ def test_two_ranks_share_one_gpu_data_parallel(gpu_device):
     assert r.returncode == 0 and "check: OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.timeout(900)
+def test_stock_ddp_nerf_stages_and_main_py_optimiser_protocol(gpu_device):
+    """main.py:60-62 + :176-207 + :78-89 on the HIP path: MC_Model wrapped in stock DistributedDataParallel(find_unused_parameters=True),
+    the three RAdam / ExponentialLR sets with the reference's requires_grad_ toggles, two steps of each stage on two gloo ranks
+    sharing the GPU (scripts/two_rank_ddp_one_gpu.py): replicas bit-identical, and the result equal to FlatGradSync's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "two_rank_ddp_one_gpu.py")], capture_output=True, text=True, timeout=880)
+    assert r.returncode == 0 and "check: OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_flat_grad_sync_through_rccl_with_one_rank(gpu_device):
+    """backend="nccl" (= RCCL) with world_size 1 on the 1-GPU box: FlatGradSync(force_collective=True) takes the collective
+    path -- arena assembly, the flat all_reduce on an RCCL communicator, the flag read-back, .grad re-pointing -- and must
+    leave exactly the gradients a plain backward produces."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+from mc_nerf_amd import distributed as D, synthetic as S
+from mc_nerf_amd.model import MC_Model, MC_NeRF_Loss
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1)
+sp = S.make_sys_param(dev, samples=32, scale=2, batch=512, H=32, W=32, coarse=(4, 32, [2]), fine=(8, 64, [4]), precision="f16x3")
+torch.manual_seed(1); model = MC_Model(sp).to(dev); S.init_cameras_near_gt(model, noise=1e-3)
+wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0]); wpts, pts = wpts.to(dev), pts.to(dev)
+img = torch.rand(1, 32 * 32, 3, device=dev)
+def grads(sync):
+    torch.manual_seed(5)
+    for p in model.parameters(): p.grad = None
+    if sync: sync.prepare()
+    loss_dict, *_ = model((img, torch.tensor([3]), wpts, pts, wpts, pts), 20, "GLOBAL_OPTIM_EPOCH", 0.6)
+    MC_NeRF_Loss(sp)(loss_dict, "GLOBAL_OPTIM_EPOCH").backward()
+    if sync: sync.sync()
+    return {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()}
+plain = grads(None)
+s = D.FlatGradSync(model, 1, force_collective=True)
+via = grads(s)
+assert dist.get_backend() == "nccl"
+for n in plain:
+    assert (plain[n] is None) == (via[n] is None), n
+    if plain[n] is not None:
+        assert torch.allclose(plain[n], via[n], rtol=1e-4, atol=1e-7), n      # (weight-gradient atomics: summation order)
+assert s.asymmetric_steps() == 0
+dist.destroy_process_group()
+print("rccl-1-rank: OK")
+""" % root
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl-1-rank: OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_bench_two_ranks_share_one_gpu(gpu_device):
     """`python bench.py --gpus 2` end to end on the one-GPU box: the parent starts two rank processes, they rendezvous (gloo here:
     RCCL needs one GPU per rank), shard the cameras, run the step loop with the gradient sync, and rank 0 prints the JSON line with
@@ -727,11 +785,15 @@ def test_inference_and_sigma2weights_api(gpu_device, precision):
         xyz = o.unsqueeze(1) + d.unsqueeze(1) * z.unsqueeze(2)
         idx = None if coarse else torch.nonzero(torch.rand(n, z.shape[1], generator=torch.Generator().manual_seed(1)) < 0.4)
         rgb, sig, depth, opac, _ = O.inference(p, net, cfg, 1.0, o, d, z, eps, idx)
-        got = m.inference(model, m.emmbedding_xyz, 1.0, xyz.to(dev), d.to(dev), z.to(dev),
-                          None if idx is None else idx.to(dev), coarse, eps=eps.to(dev))
+        with torch.no_grad():
+            got = m.inference(model, m.emmbedding_xyz, 1.0, xyz.to(dev), d.to(dev), z.to(dev),
+                              None if idx is None else idx.to(dev), coarse, eps=eps.to(dev))
         assert err(got[0], rgb.numpy()) < TOL and err(got[3], depth.numpy()) < TOL and err(got[4], opac.numpy()) < TOL
         assert err(got[1], sig.numpy()) < 1e-4 * max(1.0, float(sig.abs().max()))
         assert got[2].shape == xyz.shape
+    from mc_nerf_amd._lib import McnerfError
+    with pytest.raises(McnerfError, match="forward-only"):        # (reference :682-727 is differentiable; this one says so instead of detaching)
+        m.inference(m.nerf_coarse, m.emmbedding_xyz, 1.0, xyz.to(dev), d.to(dev), z.to(dev), None, True)
     dl, sg, ep = torch.rand(7, 16) + 0.05, torch.randn(7, 16) * 3, torch.randn(7, 16)
     assert err(m.sigma2weights(dl.to(dev), sg.to(dev), ep.to(dev)), O.sigma2weights(dl, sg, ep).numpy()) < 2e-6
     # arbitrary sample positions (not grid + jitter, a sample count of its own): the general path on the stand-alone kernels
@@ -741,8 +803,9 @@ def test_inference_and_sigma2weights_api(gpu_device, precision):
     e7 = torch.randn(n, 7, generator=g7)
     for idx in (None, torch.nonzero(torch.rand(n, 7, generator=g7) < 0.5)):
         rgb, sig, depth, opac, _ = O.inference(pc, cfg.coarse, cfg, 0.5, o, d, z7, e7, idx)
-        got = m.inference(m.nerf_coarse, m.emmbedding_xyz, 0.5, xyz7.to(dev), d.to(dev), z7.to(dev),
-                          None if idx is None else idx.to(dev), True, eps=e7.to(dev))
+        with torch.no_grad():
+            got = m.inference(m.nerf_coarse, m.emmbedding_xyz, 0.5, xyz7.to(dev), d.to(dev), z7.to(dev),
+                              None if idx is None else idx.to(dev), True, eps=e7.to(dev))
         assert err(got[0], rgb.numpy()) < TOL and err(got[3], depth.numpy()) < TOL and err(got[4], opac.numpy()) < TOL
         assert err(got[1], sig.numpy()) < 1e-4 * max(1.0, float(sig.abs().max()))
 
@@ -892,6 +955,15 @@ def test_standalone_module_forwards_match_reference_modules(gpu_device):
         net = CorseFine_NeRF(sp, type=typ).to(dev)
         p = O.init_params(nc, seed)
         net.load_state_dict(p)
-        out = net(x_enc.to(dev), dirs.to(dev))
+        with torch.no_grad():
+            out = net(x_enc.to(dev), dirs.to(dev))
         ref = O.mlp_forward(p, nc, x_enc, dirs)
         assert out.shape == (777, 4) and float((out.cpu() - ref).abs().max()) < 2e-5
+        # the stand-alone forwards have no backward (the differentiable path is the fused render): a caller that would train
+        # through them gets an error, never a silently detached tensor
+        from mc_nerf_amd._lib import McnerfError
+        with pytest.raises(McnerfError, match="forward-only"):
+            net(x_enc.to(dev), dirs.to(dev))                        # parameters require grad, autograd is recording
+    with pytest.raises(McnerfError, match="forward-only"):
+        emb(x.to(dev).requires_grad_(True), 0.5)
+    assert not emb(x.to(dev), 0.5).requires_grad                   # nothing requires a gradient: plain inference call
