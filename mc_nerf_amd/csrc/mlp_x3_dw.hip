@@ -7,8 +7,8 @@
 // Same streaming structure as mlp16_dw.hip (one launch per net; the segments' 32-row tiles form one linear sequence cut
 // into gridDim.x pieces; persistent 8-wave workgroup per CU; LDS ring of whole tiles filled by LDS-DMA with the
 // non-temporal policy; both operands read with ds_read_b64_tr_b16; a block flushed with fp32 atomics when a workgroup's
-// piece leaves a segment).  A tile is now 2 (N + K) / 16 pieces of 1 KiB (the hi pieces of dY and X, then the lo pieces),
-// so the ring holds as many stages as fit 160 KiB (2 for the 256 x 256 blocks).
+// piece leaves a segment).  A tile is now 2 (N + K) / 16 pieces of 1 KiB, which leaves room for only 2 tile slots in the
+// CU's 160 KiB at 256 x 256 -- so the slots are filled, consumed and freed by QUARTERS (dwx3_run).
 #include "mcnerf_x3.h"
 
 struct DwX3Seg {
@@ -34,21 +34,43 @@ constexpr int dwx3_pick(int N, int K, bool want_vn) {
         }
     return want_vn ? bestVN : bestKT;
 }
-constexpr int dwx3_stages(int pieces) {            // ring stages of `pieces` KiB that fit the CU's LDS (at most 4)
+constexpr int dwx3_slots(int pieces) {             // tile slots of `pieces` KiB that fit the CU's LDS (2 .. 4)
     const int s = 160 / pieces;
     return s > 4 ? 4 : (s < 2 ? 2 : s);
 }
 
+// s_waitcnt vmcnt(NX * cx + NY * cy) + s_barrier with this wave's piece counts per X / dY quarter (cx in {PWX, PWX - 1}, cy in
+// {PWY, PWY - 1}; wave-uniform) as immediates
+template <int NX, int NY, int PWX, int PWY>
+__device__ __forceinline__ void dwx3_wait(bool full_x, bool full_y, bool steady) {
+#define DWX3_W(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
+    if (!steady) DWX3_W(0);
+    else if (full_x && full_y) DWX3_W(NX * PWX + NY * PWY);
+    else if (full_x) DWX3_W(NX * PWX + NY * (PWY > 0 ? PWY - 1 : 0));
+    else if (full_y) DWX3_W(NX * (PWX > 0 ? PWX - 1 : 0) + NY * PWY);
+    else DWX3_W(NX * (PWX > 0 ? PWX - 1 : 0) + NY * (PWY > 0 ? PWY - 1 : 0));
+#undef DWX3_W
+}
+
 // tiles [t0, t1) of one segment: stream, accumulate, flush.
+// A tile's four operand planes are QUARTERS of a tile slot, issued, consumed and freed in the order
+//     X_lo, dY_hi, X_hi, dY_lo:   step A  acc += dY_hi X_lo  (frees X_lo)
+//                                 step B  acc += dY_hi X_hi  (frees dY_hi)
+//                                 step C  acc += dY_lo X_hi  (frees X_hi, dY_lo)
+// so a freed quarter is refilled (tile + R) at once, one step = one third of a tile's MFMAs after it was last read: with the
+// R = 2 slots that a 256 x 256 block leaves room for, 80-96 KiB are in flight per CU at any time instead of one whole tile
+// (64 KiB) issued once per tile.  One counted vmcnt wait + raw barrier per step; leaves no LDS-DMA piece outstanding and every
+// wave past the barrier that follows the last LDS read.
 template <int N, int K1, int K2>
 __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const int t1, const float sgs, char* smem) {
     constexpr int K = K1 + K2;
-    constexpr int KSN = N / 16, KSK1 = K1 / 16, KSK2 = K2 / 16, P = KSN + KSK1 + KSK2, P2 = 2 * P;   // 1 KiB pieces per tile
-    constexpr int PW = (P2 + MCN16_WAVES - 1) / MCN16_WAVES;
+    constexpr int KSN = N / 16, KSK1 = K1 / 16, KSK2 = K2 / 16, KSK = KSK1 + KSK2, P2 = 2 * (KSN + KSK);   // 1 KiB pieces per tile
+    constexpr int PWX = (KSK + MCN16_WAVES - 1) / MCN16_WAVES, PWY = (KSN + MCN16_WAVES - 1) / MCN16_WAVES;   // pieces per wave and quarter
     constexpr int VN = dwx3_pick(N, K, true), KT = dwx3_pick(N, K, false);
     constexpr int NG = N / (32 * VN), KG = K / (32 * KT), G = NG * KG, MS = MCN16_WAVES / G;
     static_assert(G >= 1 && MCN16_WAVES % G == 0, "wave tiling");
-    constexpr int STAGE = P2 * 1024, ST = dwx3_stages(P2), AH = ST - 1;
+    constexpr int SLOT = P2 * 1024, R = dwx3_slots(P2);
+    constexpr int oXlo = 0, oYhi = KSK * 1024, oXhi = (KSK + KSN) * 1024, oYlo = (2 * KSK + KSN) * 1024;
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
 
@@ -56,34 +78,48 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
     const int gi = wave % G, ms = wave / G;
     const int nbase = (gi % NG) * 32 * VN, kbase = (gi / NG) * 32 * KT;
 
-    // ---- LDS-DMA pieces of this wave: piece pi = wave + 8 i; pieces 0 .. P-1 = hi (dY, X, X2 fragments), P .. 2P-1 = lo
+    // ---- LDS-DMA pieces of this wave: piece i of a quarter = fragment wave + 8 i of that operand plane
     const unsigned lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem);
-    const char* src[PW];
-    int step[PW];
     const int hh = lane >> 5, mm = lane & 31;
+    const int nx = (KSK > wave) ? (KSK - wave + MCN16_WAVES - 1) / MCN16_WAVES : 0;        // wave-uniform piece counts
+    const int ny = (KSN > wave) ? (KSN - wave + MCN16_WAVES - 1) / MCN16_WAVES : 0;
+    const bool full_x = nx == PWX, full_y = ny == PWY;
+    const char* sxl[PWX > 0 ? PWX : 1]; const char* sxh[PWX > 0 ? PWX : 1];
+    const char* syl[PWY > 0 ? PWY : 1]; const char* syh[PWY > 0 ? PWY : 1];
+    int stx[PWX > 0 ? PWX : 1];
 #pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        const int pi = wave + MCN16_WAVES * i;
-        const int part = pi >= P ? 1 : 0, q = pi - part * P;
-        const int which = q < KSN ? 0 : (q < KSN + KSK1 ? 1 : 2);
-        const int s = which == 0 ? q : (which == 1 ? q - KSN : q - KSN - KSK1);
-        const int ks = which == 0 ? KSN : (which == 1 ? KSK1 : KSK2);
+    for (int i = 0; i < PWX; ++i) {
+        const int f = wave + MCN16_WAVES * i;                          // fragment of [X | X2]
+        const bool two = f >= KSK1;
+        const int s = two ? f - KSK1 : f, ks = two ? KSK2 : KSK1;
         const int m_src = mm ^ (4 * (2 * (s & 1) + hh));
-        const char* base = which == 0 ? sg.dY : (which == 1 ? sg.X : sg.X2);
-        src[i] = (pi < P2 && base) ? base + ((size_t)t0 * 2 * ks + part * ks + s) * 1024 + (hh * 32 + m_src) * 16 : nullptr;
-        step[i] = 2 * ks * 1024;
+        const char* base = (two ? sg.X2 : sg.X);
+        const char* p0 = base ? base + ((size_t)t0 * 2 * ks + s) * 1024 + (hh * 32 + m_src) * 16 : nullptr;
+        sxh[i] = p0; sxl[i] = p0 ? p0 + (size_t)ks * 1024 : nullptr;
+        stx[i] = 2 * ks * 1024;
     }
-    const int np = (P2 % MCN16_WAVES == 0 || wave < P2 % MCN16_WAVES) ? PW : PW - 1;      // wave-uniform
-    auto fill = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int pi = wave + MCN16_WAVES * i;
-            if (i < np) mcn16_dma16_nt(src[i], lds_base + stage * STAGE + pi * 1024);
-            src[i] += step[i];
+    for (int i = 0; i < PWY; ++i) {
+        const int s = wave + MCN16_WAVES * i;
+        const int m_src = mm ^ (4 * (2 * (s & 1) + hh));
+        const char* p0 = sg.dY + ((size_t)t0 * 2 * KSN + s) * 1024 + (hh * 32 + m_src) * 16;
+        syh[i] = p0; syl[i] = p0 + (size_t)KSN * 1024;
+    }
+    // quarter q of the NEXT tile to issue for it (each quarter keeps its own tile cursor through its source pointers)
+    auto issue_x = [&](const char* (&src)[PWX > 0 ? PWX : 1], int slot, int off) {
+#pragma unroll
+        for (int i = 0; i < PWX; ++i) {
+            if (i < nx) mcn16_dma16_nt(src[i], lds_base + slot * SLOT + off + (wave + MCN16_WAVES * i) * 1024);
+            src[i] += stx[i];
         }
     };
-#define DWX3_WAIT_ASM(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
-#define DWX3_WAIT(k) do { if (np == PW) DWX3_WAIT_ASM((k) * PW); else DWX3_WAIT_ASM((k) * (PW - 1)); } while (0)
+    auto issue_y = [&](const char* (&src)[PWY > 0 ? PWY : 1], int slot, int off) {
+#pragma unroll
+        for (int i = 0; i < PWY; ++i) {
+            if (i < ny) mcn16_dma16_nt(src[i], lds_base + slot * SLOT + off + (wave + MCN16_WAVES * i) * 1024);
+            src[i] += 2 * KSN * 1024;
+        }
+    };
 
     f32x16 acc[VN][KT];
     mcn_zero<VN, KT>(acc);
@@ -104,65 +140,86 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
             const int m = 16 * u + 8 * (g16 >> 1) + 4 * v + q;
             roff[u][v] = (hp * 32 + (m ^ cxor)) * 16 + 8 * (p >> 1);
         }
-    const int fragA0 = (nbase / 16) + (g16 & 1);
-    const int fragB0 = KSN + (kbase / 16) + (g16 & 1);
-
-    int nt = t1 - t0;
-#pragma unroll
-    for (int i = 0; i < AH; ++i)
-        if (i < nt) fill(i);
-    {
-        const int younger = min(nt, AH) - 1;
-        if (younger >= 2) DWX3_WAIT(2); else if (younger == 1) DWX3_WAIT(1); else DWX3_WAIT(0);
-    }
-    static_assert(AH <= 3, "wait ladder covers up to 2 younger tiles");
-    int cur = 0;
+    const int fragA0 = (nbase / 16) + (g16 & 1);                      // first dY fragment of this lane
+    const int fragB0 = (kbase / 16) + (g16 & 1);                      // first [X | X2] fragment of this lane
     auto frag = [&](const char* fp, int u) -> u32x4_t {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(fp + roff[u][0]));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(fp + roff[u][1]));
         const u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
         return u32x4_t{l2[0], l2[1], h2[0], h2[1]};
     };
+    auto colsum = [&](const u32x4_t& v, float& sacc) {              // the 8 samples of this lane's dY column
+        const f16x2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+        const f16x8_t hv = __builtin_bit_cast(f16x8_t, v);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) sacc = __builtin_amdgcn_fdot2(f16x2_t{hv[2 * d], hv[2 * d + 1]}, ones, sacc, false);
+    };
+
+    const int nt = t1 - t0;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        if (i < nt) { issue_x(sxl, i, oXlo); issue_y(syh, i, oYhi); issue_x(sxh, i, oXhi); issue_y(syl, i, oYlo); }
+    int slot = 0;
     for (int it = 0; it < nt; ++it) {
-        if (it + AH < nt) fill((cur + AH) % ST);
-        if ((it % MS) == ms) {                                        // wave-uniform: waves sharing an output tile alternate tiles
-            const char* st = smem + cur * STAGE;
+        const bool mine = (it % MS) == ms;                            // wave-uniform: waves sharing an output tile alternate tiles
+        const char* st = smem + slot * SLOT;
+        const int pslot = (slot + R - 1) % R;                         // the previous tile's slot
+        u32x4_t ah[2][VN], bx[2][KT];
+        // ---- step A: dY_hi X_lo.  Landed: X_lo, dY_hi of this tile; every wave is past step C of the previous tile
+        dwx3_wait<2 * R - 2, 2 * R - 2, PWX, PWY>(full_x, full_y, it + R - 1 < nt);
+        if (it >= 1 && it - 1 + R < nt) { issue_x(sxh, pslot, oXhi); issue_y(syl, pslot, oYlo); }
+        if (mine) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                u32x4_t ah[VN], al[VN], bh[KT], bl[KT];
 #pragma unroll
-                for (int t = 0; t < VN; ++t) {
-                    ah[t] = frag(st + (fragA0 + 2 * t) * 1024, u);
-                    al[t] = frag(st + (P + fragA0 + 2 * t) * 1024, u);
-                }
+                for (int t = 0; t < VN; ++t) ah[u][t] = frag(st + oYhi + (fragA0 + 2 * t) * 1024, u);
 #pragma unroll
-                for (int t = 0; t < KT; ++t) {
-                    bh[t] = frag(st + (fragB0 + 2 * t) * 1024, u);
-                    bl[t] = frag(st + (P + fragB0 + 2 * t) * 1024, u);
-                }
-#pragma unroll
-                for (int t = 0; t < VN; ++t) {
-                    if (bias) {          // column sums of dY: the 8 samples of this lane's column, hi + lo
-                        const f16x2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
-                        const f16x8_t hv = __builtin_bit_cast(f16x8_t, ah[t]), lv = __builtin_bit_cast(f16x8_t, al[t]);
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            bsum[t] = __builtin_amdgcn_fdot2(f16x2_t{hv[2 * d], hv[2 * d + 1]}, ones, bsum[t], false);
-                            bsum[t] = __builtin_amdgcn_fdot2(f16x2_t{lv[2 * d], lv[2 * d + 1]}, ones, bsum[t], false);
-                        }
-                    }
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) mcnx3_mfma3(acc[t][kt], ah[t], al[t], bh[kt], bl[kt]);
-                }
+                for (int t = 0; t < KT; ++t) bx[u][t] = frag(st + oXlo + (fragB0 + 2 * t) * 1024, u);
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < VN; ++t) {
+                    if (bias) colsum(ah[u][t], bsum[t]);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) acc[t][kt] = mcnx3_mfma(ah[u][t], bx[u][kt], acc[t][kt]);
+                }
         }
-        const int left = nt - 1 - it;
-        const int younger = min(left, AH) - 1;
-        if (younger >= 2) DWX3_WAIT(2); else if (younger == 1) DWX3_WAIT(1); else DWX3_WAIT(0);
-        cur = (cur + 1) % ST;
+        // ---- step B: dY_hi X_hi.  Landed: X_hi; every wave is past step A: X_lo of this slot is free
+        dwx3_wait<2 * R - 2, 2 * R - 1, PWX, PWY>(full_x, full_y, it + R - 1 < nt);
+        if (it + R < nt) issue_x(sxl, slot, oXlo);
+        if (mine) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < KT; ++t) bx[u][t] = frag(st + oXhi + (fragB0 + 2 * t) * 1024, u);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < VN; ++t)
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) acc[t][kt] = mcnx3_mfma(ah[u][t], bx[u][kt], acc[t][kt]);
+        }
+        // ---- step C: dY_lo X_hi.  Landed: dY_lo; every wave is past step B: dY_hi of this slot is free
+        dwx3_wait<2 * R - 1, 2 * R - 2, PWX, PWY>(full_x, full_y, it + R < nt);
+        if (it + R < nt) issue_y(syh, slot, oYhi);
+        if (mine) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < VN; ++t) ah[u][t] = frag(st + oYlo + (fragA0 + 2 * t) * 1024, u);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < VN; ++t) {
+                    if (bias) colsum(ah[u][t], bsum[t]);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) acc[t][kt] = mcnx3_mfma(ah[u][t], bx[u][kt], acc[t][kt]);
+                }
+        }
+        slot = (slot + 1) % R;
     }
-#undef DWX3_WAIT
-#undef DWX3_WAIT_ASM
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // every wave has finished its last LDS read: the next run may refill
     // ---- accumulators -> global (float atomics; one register = two 128-byte row segments)
     const int r = lane & 31, h = lane >> 5;
     const float inv = 1.0f / (sgs * MCNX3_SX), inv_b = 1.0f / sgs;
@@ -246,7 +303,7 @@ static hipError_t dwx3_launch_job(const DwX3Job& job, const int* count, int rows
     // LDS: the largest stages x stage product over the shapes of this width
     constexpr int KS = W / 16;
     constexpr int p0 = 2 * (2 * KS), p1 = 2 * (KS + MCN16_ENCKS), p2 = 2 * (2 + KS), p3 = 2 * (2 * KS + MCN16_ENCKS);
-    constexpr int l0 = dwx3_stages(p0) * p0, l1 = dwx3_stages(p1) * p1, l2 = dwx3_stages(p2) * p2, l3 = DwX3SkipMerged<W>::value ? dwx3_stages(p3) * p3 : 0;
+    constexpr int l0 = dwx3_slots(p0) * p0, l1 = dwx3_slots(p1) * p1, l2 = dwx3_slots(p2) * p2, l3 = DwX3SkipMerged<W>::value ? dwx3_slots(p3) * p3 : 0;
     constexpr int lmax = (l0 > l1 ? l0 : l1) > (l2 > l3 ? l2 : l3) ? (l0 > l1 ? l0 : l1) : (l2 > l3 ? l2 : l3);
     static_assert(lmax <= 160, "ring exceeds the CU's LDS");
     const size_t lds = (size_t)lmax * 1024;
