@@ -99,7 +99,11 @@ __device__ __forceinline__ void mcnx3_ring_issue(Mcn16Ring& r) {
 }
 template <int PPW>
 __device__ __forceinline__ void mcnx3_ring_sync(Mcn16Ring& r) {
+#ifdef MCNX3_EXP_VMCNT          // (timing experiment only, NOT safe: another wait count)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MCNX3_EXP_VMCNT) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW * (MCN16_AHEAD - 1)) : "memory");
+#endif
     r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
     r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
     mcnx3_ring_issue<PPW>(r);
