@@ -1,7 +1,7 @@
 """Per-kernel means of the SQ counters collected by scripts/pmc_sq.sh:  python scripts/pmc_sq_summary.py gpurun_out/sq_base [filter]"""
 import csv, glob, sys, re
 from collections import defaultdict
-d = sys.argv[1]; flt = sys.argv[2] if len(sys.argv) > 2 else "mlp_|dw_"
+d = sys.argv[1]; flt = sys.argv[2] if len(sys.argv) > 2 else "mlp|dw"
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):

@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage (GPU box, repo root): scripts/r03_evidence.sh <tag>
+# One snapshot of the measurement evidence at the current sources: the default bench line, rocprofv3 kernel stats of the same
+# command (headline mode and f16), HBM traffic (separate PMC passes) and SQ counters of the fine-net kernels.
+TAG=${1:-r03}
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+python3 bench.py --steps 50 --warmup 5 2> gpurun_out/${TAG}_bench_default.err | tail -1 > gpurun_out/${TAG}_bench_default.json
+for P in f16x3 f16; do
+  scripts/prof_bench.sh ${TAG}_$P --steps 10 --warmup 3 --also= --no-cpu-baseline --precision $P > gpurun_out/${TAG}_kernel_table_$P.txt 2>&1
+  cp gpurun_out/prof_${TAG}_$P/kernel_stats.csv gpurun_out/${TAG}_kernel_stats_$P.csv
+  scripts/pmc_bench.sh $TAG $P > gpurun_out/${TAG}_pmc_table_$P.txt 2>&1
+done
+mkdir -p gpurun_out/sq_$TAG
+scripts/pmc_sq.sh $TAG f16x3 25600 256 > /dev/null 2>&1
+python3 scripts/pmc_sq_summary.py gpurun_out/sq_$TAG > gpurun_out/${TAG}_sq_counters_f16x3.txt 2>&1
+ls -la gpurun_out | tail -20
