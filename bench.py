@@ -114,7 +114,7 @@ class KernelTimer:
         timer = self
 
         def timed(name, *args):
-            base = name.replace("_f16x3", "").replace("_16", "")
+            base = name.replace("_16", "")
             if not timer.enabled or base not in timer.BASES:
                 return orig(name, *args)
             key = (base[len("mcnerf_mlp_"):], args[1])           # (fwd | bwd | dw, net width)
@@ -512,7 +512,7 @@ def main():
     ap.add_argument("--img", type=int, default=800, help="image side (BASELINE cfg 5: 1600)")
     ap.add_argument("--rig", default="ball", choices=["ball", "array", "halfball", "room"], help="camera rig of the synthetic scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16", "bf16", "f16x3r1"],
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16", "bf16"],
                     help="MFMA mode of the MLP kernels: split-f16 f16x3 (fp32-grade, the headline: the reference computes in fp32) or "
                          "exact f32 -- the 1e-4 parity modes; single-pass f16 / bf16 -- 16-bit operand modes with their own stated error")
     ap.add_argument("--also", default="f16,bf16,f32", help="other precision modes measured in the same run (by_precision)")

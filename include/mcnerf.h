@@ -46,11 +46,6 @@ int mcnerf_param_offsets(int depth, int width, int skip, long long* offsets);
  * counterpart (torch's addmm reads nn.Linear.weight directly, model/net_block.py:69-74). */
 int mcnerf_pack_weights(int depth, int width, int skip, const float* params, float* packed, void* stream);
 
-/* Split-f16 ("f16x3") precision mode: the same weights re-laid as hi/lo f16 fragments scaled by 2^8 for
- * v_mfma_f32_32x32x16_f16 (three MFMAs per product, fp32 accumulate: ~2^-21 relative product error at 5.3x
- * the exact-fp32 MFMA rate).  `packed16` has the byte size of `packed` (mcnerf_packed_count * 4). */
-int mcnerf_pack_weights_f16x3(int depth, int width, int skip, const float* params, void* packed16, void* stream);
-
 /* Ray generation for the selected pixels of ONE camera.
  * Replaces MC_Model.get_rays + generate_rand_rays (model/mc_nerf.py:124-145, 327-345):
  * pose [3,4] = world->cam [R|t], kinv [3,3], pix [n] = v*W+u  ->  rays_d [n,3] (unit), rays_o [n,3]. */
@@ -96,15 +91,6 @@ int mcnerf_upload_f32(float* dst, const float* host_vals, int n, void* stream);
 int mcnerf_mlp_apply(int depth, int width, int skip, const float* params, const float* packed, const float* x_enc,
                      const float* dirs, int n, float* out, void* stream);
 
-/* mcnerf_mlp_fwd in the split-f16 precision mode: identical arguments, outputs and workspace formats;
- * `packed16` comes from mcnerf_pack_weights_f16x3.  Activations must stay below 8188 in magnitude. */
-int mcnerf_mlp_fwd_f16x3(int depth, int width, int skip, const float* params, const void* packed16,
-                         const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
-                         const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
-                         int n_rays, int S, float* out,
-                         float* act_save, long long capacity, float* enc_save, float* sh_save, uint32_t* mask_save,
-                         void* stream);
-
 /* Backward of mcnerf_mlp_fwd wrt the activations (the dX chain): consumes d_out [n_rays,S,4],
  * writes the pre-activation gradients of every layer to dy_save ((depth+2)*capacity*width floats) and
  * dsh_save (capacity*32: d sh.2 outputs in columns 0..26, d sigma_raw in column 27) and ACCUMULATES
@@ -118,28 +104,12 @@ int mcnerf_mlp_bwd(int depth, int width, int skip, const float* params, const fl
                    const uint32_t* mask_save, long long capacity, const float* enc_save, const float* sh_save,
                    float* dy_save, float* dsh_save, float* d_rays_o, float* d_rays_d, void* stream);
 
-/* mcnerf_mlp_bwd in the split-f16 precision mode: same arguments plus gmax_bits (device word: float bits of
- * max |d_out|, from mcnerf_composite_bwd), from which the kernel derives its power-of-two gradient scale. */
-int mcnerf_mlp_bwd_f16x3(int depth, int width, int skip, const float* params, const void* packed16,
-                         const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
-                         const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
-                         int n_rays, int S, const float* out, const float* d_out,
-                         const uint32_t* mask_save, long long capacity, const float* enc_save, const float* sh_save,
-                         float* dy_save, float* dsh_save, float* d_rays_o, float* d_rays_d, const uint32_t* gmax_bits,
-                         void* stream);
-
 /* Weight / bias gradients of one net: dW_l = dY_l^T X_l, db_l = sum_rows dY_l, ACCUMULATED into
  * `grads` (flat, same layout as the parameters; caller zeroes it once per step).
  * `count` NULL -> `rows` rows are valid; otherwise *count (<= rows). */
 int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows,
                   const float* act_save, const float* enc_save, const float* dy_save, const float* dsh_save,
                   long long capacity, float* grads, void* stream);
-
-/* mcnerf_mlp_dw in the split-f16 precision mode (same fp32 operands; fragments are split to hi/lo f16 in
- * registers, three f16 MFMAs per product); gmax_bits as for mcnerf_mlp_bwd_f16x3. */
-int mcnerf_mlp_dw_f16x3(int depth, int width, int skip, const int32_t* count, int rows,
-                        const float* act_save, const float* enc_save, const float* dy_save, const float* dsh_save,
-                        long long capacity, float* grads, const uint32_t* gmax_bits, void* stream);
 
 /* ---- Register-chain modes (csrc/mcnerf_16.h, csrc/mcnerf_x3.h), selected by `dtype`:
  *   0 = f16, 1 = bf16: ONE v_mfma_f32_32x32x16_{f16|bf16} per product, fp32 accumulate, biases / epilogues / outputs in
@@ -187,7 +157,7 @@ int mcnerf_composite_fwd(const float* sig_rgb, const float* rays_d, const float*
                          const float* eps, const float* eps_sel, int N, int S, int white_back,
                          float* rgb, float* depth, float* opacity, float* w_sel, uint32_t* wmax_bits, void* stream);
 /* Backward of the rgb composite: d_rgb [N,3] -> d_sig_rgb [N,S,4].  gmax_bits (or NULL): max |d_sig_rgb| of the
- * launch as float bits, max-reduced into a caller-zeroed word (the gradient scale of mcnerf_mlp_bwd_f16x3). */
+ * launch as float bits, max-reduced into a caller-zeroed word (the gradient scale of mcnerf_mlp_bwd_16). */
 int mcnerf_composite_bwd(const float* sig_rgb, const float* zgrid, const float* jitter, const float* eps,
                          const float* d_rgb, int N, int S, int white_back, float* d_sig_rgb, uint32_t* gmax_bits,
                          void* stream);

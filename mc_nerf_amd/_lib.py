@@ -30,7 +30,6 @@ SIGNATURES = {
     "mcnerf_tile_rows": (_I, [_I]),
     "mcnerf_param_offsets": (_I, [_I, _I, _I, _P]),
     "mcnerf_pack_weights": (_I, [_I, _I, _I, _P, _P, _P]),
-    "mcnerf_pack_weights_f16x3": (_I, [_I, _I, _I, _P, _P, _P]),
     "mcnerf_raygen_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "mcnerf_raygen_bwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "mcnerf_mlp_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
@@ -40,13 +39,9 @@ SIGNATURES = {
     "mcnerf_scale3": (_I, [_P, _I, _P, _I, _P, _I, _P, _P]),
     "mcnerf_sample_perm": (_I, [_P, ctypes.c_longlong, _I, _P, _P]),
     "mcnerf_mlp_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
-    "mcnerf_mlp_fwd_f16x3": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
     "mcnerf_mlp_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,
                             _P, _P, _P, _P, _P]),
-    "mcnerf_mlp_bwd_f16x3": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,
-                                  _P, _P, _P, _P, _P, _P]),
     "mcnerf_mlp_dw": (_I, [_I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P]),
-    "mcnerf_mlp_dw_f16x3": (_I, [_I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P]),
     "mcnerf_packed_bytes_16": (_L, [_I, _I, _I, _I, _I]),
     "mcnerf_pack_weights_16": (_I, [_I, _I, _I, _P, _P, _P, _I, _P]),
     "mcnerf_ws_bytes_16": (_L, [_I, _I, _I, _L, _I]),

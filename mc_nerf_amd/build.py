@@ -12,8 +12,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmcnerf.so")
-SOURCES = ["api.hip", "pack.hip", "mlp_fwd.hip", "mlp_fwd_h.hip", "mlp_bwd.hip", "mlp_bwd_h.hip", "mlp_dw.hip", "pack16.hip", "mlp16_fwd.hip", "mlp16_bwd.hip", "mlp16_dw.hip", "mlp_x3_fwd.hip", "mlp_x3_bwd.hip", "mlp_x3_dw.hip", "composite.hip", "select_raygen.hip", "optim.hip", "camera.hip"]
-HEADERS = ["mcnerf_common.h", "mcnerf_kernels.h", "mcnerf_h.h", "mcnerf_16.h", "mcnerf_x3.h", os.path.join("..", "..", "include", "mcnerf.h")]
+SOURCES = ["api.hip", "pack.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_dw.hip", "pack16.hip", "mlp16_fwd.hip", "mlp16_bwd.hip", "mlp16_dw.hip", "mlp_x3_fwd.hip", "mlp_x3_bwd.hip", "mlp_x3_dw.hip", "composite.hip", "select_raygen.hip", "optim.hip", "camera.hip"]
+HEADERS = ["mcnerf_common.h", "mcnerf_kernels.h", "mcnerf_16.h", "mcnerf_x3.h", os.path.join("..", "..", "include", "mcnerf.h")]
 # the f16x3 chains: a layer body is ~400 MFMAs with its epilogue slices, fully unrolled (beyond hipcc's default pragma-unroll budget);
 # their 256-wide instantiations run one wave per SIMD with 512 registers, where hipcc would otherwise put the MFMA
 # accumulators in AGPRs (every epilogue read then costs a v_accvgpr_read behind a full MFMA drain)

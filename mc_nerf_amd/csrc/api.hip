@@ -59,10 +59,6 @@ int mcnerf_pack_weights(int depth, int width, int skip, const float* params, flo
     return check("mcnerf_pack_weights", mcn_launch_pack(mcn_make_layout(depth, width, skip), params, packed, (hipStream_t)stream));
 }
 
-int mcnerf_pack_weights_f16x3(int depth, int width, int skip, const float* params, void* packed16, void* stream) {
-    REQ(net_ok(depth, width, skip) && params && packed16, "mcnerf_pack_weights_f16x3");
-    return check("mcnerf_pack_weights_f16x3", mcn_launch_pack_h(mcn_make_layout(depth, width, skip), params, packed16, (hipStream_t)stream));
-}
 
 int mcnerf_raygen_fwd(const float* pose, const float* kinv, const int64_t* pix, int n, int W,
                       float* rays_d, float* rays_o, void* stream) {
@@ -136,27 +132,6 @@ int mcnerf_mlp_apply(int depth, int width, int skip, const float* params, const 
     return check("mcnerf_mlp_apply", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
 }
 
-int mcnerf_mlp_fwd_f16x3(int depth, int width, int skip, const float* params, const void* packed16,
-                   const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
-                   const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
-                   int n_rays, int S, float* out,
-                   float* act_save, long long capacity, float* enc_save, float* sh_save, uint32_t* mask_save, void* stream) {
-    REQ(net_ok(depth, width, skip), "mcnerf_mlp_fwd_f16x3");
-    REQ(params && packed16 && rays_o && rays_d && zgrid && barf_w && out && n_rays >= 0 && S > 0, "mcnerf_mlp_fwd_f16x3");
-    REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_fwd_f16x3");
-    REQ(!idx || max_rows >= 0, "mcnerf_mlp_fwd_f16x3");
-    REQ((long long)n_rays * S < (1ll << 31), "mcnerf_mlp_fwd_f16x3");
-    if (act_save) {
-        REQ(enc_save && sh_save && mask_save, "mcnerf_mlp_fwd_f16x3");
-        REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_fwd_f16x3");
-    }
-    McnMlpFwdArgs a;
-    a.lay = mcn_make_layout(depth, width, skip);
-    a.params = params; a.packed = (const float*)packed16; a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter;
-    a.barf_w = barf_w; a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
-    a.out = out; a.act_save = act_save; a.act_stride = MCN_ACT_STRIDE(capacity, width); a.enc_save = enc_save; a.sh_save = sh_save; a.mask_save = mask_save;
-    return check("mcnerf_mlp_fwd_f16x3", mcn_launch_mlp_fwd_h(a, (hipStream_t)stream));
-}
 
 int mcnerf_mlp_bwd(int depth, int width, int skip, const float* params, const float* packed,
                    const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
@@ -179,26 +154,6 @@ int mcnerf_mlp_bwd(int depth, int width, int skip, const float* params, const fl
     return check("mcnerf_mlp_bwd", mcn_launch_mlp_bwd(a, (hipStream_t)stream));
 }
 
-int mcnerf_mlp_bwd_f16x3(int depth, int width, int skip, const float* params, const void* packed16,
-                   const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
-                   const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
-                   int n_rays, int S, const float* out, const float* d_out,
-                   const uint32_t* mask_save, long long capacity, const float* enc_save, const float* sh_save,
-                   float* dy_save, float* dsh_save, float* d_rays_o, float* d_rays_d, const uint32_t* gmax_bits, void* stream) {
-    REQ(net_ok(depth, width, skip), "mcnerf_mlp_bwd_f16x3");
-    REQ(params && packed16 && gmax_bits && rays_o && rays_d && zgrid && barf_w && out && d_out && n_rays >= 0 && S > 0, "mcnerf_mlp_bwd_f16x3");
-    REQ(mask_save && enc_save && sh_save && dy_save && dsh_save, "mcnerf_mlp_bwd_f16x3");
-    REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_bwd_f16x3");
-    REQ(capacity >= (idx ? (long long)max_rows : (long long)n_rays * S), "mcnerf_mlp_bwd_f16x3");
-    McnMlpBwdArgs a;
-    a.lay = mcn_make_layout(depth, width, skip);
-    a.params = params; a.packed = (const float*)packed16; a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter;
-    a.barf_w = barf_w; a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
-    a.out = out; a.d_out = d_out; a.mask_save = mask_save; a.act_stride = MCN_ACT_STRIDE(capacity, width);
-    a.enc_save = enc_save; a.sh_save = sh_save; a.dy_save = dy_save; a.dsh_save = dsh_save;
-    a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d; a.gmax_bits = gmax_bits;
-    return check("mcnerf_mlp_bwd_f16x3", mcn_launch_mlp_bwd_h(a, (hipStream_t)stream));
-}
 
 int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows,
                   const float* act_save, const float* enc_save, const float* dy_save, const float* dsh_save,
@@ -212,17 +167,6 @@ int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows
     return check("mcnerf_mlp_dw", mcn_launch_dw(a, (hipStream_t)stream));
 }
 
-int mcnerf_mlp_dw_f16x3(int depth, int width, int skip, const int32_t* count, int rows,
-                        const float* act_save, const float* enc_save, const float* dy_save, const float* dsh_save,
-                        long long capacity, float* grads, const uint32_t* gmax_bits, void* stream) {
-    REQ(net_ok(depth, width, skip), "mcnerf_mlp_dw_f16x3");
-    REQ(act_save && enc_save && dy_save && dsh_save && grads && gmax_bits && rows >= 0 && capacity >= rows, "mcnerf_mlp_dw_f16x3");
-    McnDwArgs a;
-    a.lay = mcn_make_layout(depth, width, skip);
-    a.count = count; a.rows = rows; a.act_save = act_save; a.enc_save = enc_save; a.dy_save = dy_save;
-    a.dsh_save = dsh_save; a.act_stride = MCN_ACT_STRIDE(capacity, width); a.grads = grads; a.split16 = true; a.gmax_bits = gmax_bits;
-    return check("mcnerf_mlp_dw_f16x3", mcn_launch_dw(a, (hipStream_t)stream));
-}
 
 // ---- register-chain modes: single-pass 16-bit (mcnerf_16.h; dtype 0 = f16, 1 = bf16) and split-f16 "f16x3" (mcnerf_x3.h; dtype 2)
 static bool dtype_ok(int dtype) { return dtype == 0 || dtype == 1 || dtype == 2; }

@@ -30,7 +30,6 @@ hipError_t mcn_launch_train_loss(const float* pd, const float* ptg, int np, int 
 hipError_t mcn_launch_scale3(float* a, int na, float* b, int nb, float* c, int nc, const float* g, hipStream_t st);
 hipError_t mcn_launch_upload_f32(float* dst, const float* host_vals, int n, hipStream_t st);
 hipError_t mcn_launch_mlp_fwd(const McnMlpFwdArgs& a, hipStream_t st);
-hipError_t mcn_launch_mlp_fwd_h(const McnMlpFwdArgs& a, hipStream_t st);     // split-f16 mode: a.packed = mcn_launch_pack_h output
 int mcn_mlp_tile_rows(int width);
 
 struct McnMlpBwdArgs {
@@ -59,7 +58,6 @@ struct McnMlpBwdArgs {
     const unsigned int* gmax_bits;   // split-f16 mode only: float bits of max|d_out| over the launch (device scalar)
 };
 hipError_t mcn_launch_mlp_bwd(const McnMlpBwdArgs& a, hipStream_t st);
-hipError_t mcn_launch_mlp_bwd_h(const McnMlpBwdArgs& a, hipStream_t st);     // split-f16 mode
 
 struct McnDwArgs {
     McnLayout lay;
@@ -71,13 +69,12 @@ struct McnDwArgs {
     const float* dsh_save;
     size_t act_stride;
     float* grads;             // flat gradient buffer (same layout as params), accumulated with atomics
-    bool split16;             // split-f16 MFMA mode (mcnerf_h.h)
+    bool split16;             // (unused: the split-f16 mode lives in mlp_x3_dw.hip)
     const unsigned int* gmax_bits;   // split-f16 mode: float bits of max|d_out| (gradient scale), device scalar
 };
 hipError_t mcn_launch_dw(const McnDwArgs& a, hipStream_t st);
 
 hipError_t mcn_launch_pack(const McnLayout& lay, const float* params, float* packed, hipStream_t st);
-hipError_t mcn_launch_pack_h(const McnLayout& lay, const float* params, void* packed_f16, hipStream_t st);   // split-f16 (mcnerf_h.h)
 
 struct McnCompositeArgs {
     const float* sig_rgb;     // [N,S,4]

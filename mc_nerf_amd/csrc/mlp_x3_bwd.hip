@@ -19,7 +19,8 @@ struct BwdX3Smem {
     static constexpr int MW = W >= 64 ? W / 64 : 1;                 // mask dwords per lane and slot
     static constexpr int oMask = oBarf + 16 * 4;                    // per wave: 3 buffers of [MW][64] dwords (ReLU bits, fetched ahead by LDS-DMA)
     static constexpr int oIdx = oMask + WAVES * 3 * MW * 256;       // per wave: the NEXT pass's (ray, sample) pairs [32][2] (LDS-DMA, one pass ahead)
-    static constexpr int total = oIdx + WAVES * 256;
+    static constexpr int oIn = oIdx + WAVES * 256;                  // per wave (wide net): the next pass's per-sample inputs, 16 x [64 lanes] dwords (LDS-DMA gathers)
+    static constexpr int total = oIn + (W >= 256 ? WAVES * 16 * 256 : 0);
 };
 
 // GEMM over one segment of NTILES output tiles x KSTEPS contraction steps (B fragment pairs `in`), software-pipelined like
@@ -169,13 +170,52 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         const long long g_ = (pass_ * WAVES + wave) * 32 + m;
         return g_ < total ? g_ : total - 1;
     };
+    // Wide net (one wave per SIMD, ReLU bits by LDS-DMA): the gathers go through LDS-DMA too, so that NOTHING in the pass loop is a
+    // compiler-visible load -- a pass then never drains the wave's vector-memory queue (the workspace stores of a pass take
+    // microseconds to retire; a vmcnt(0) per pass waits for all of them, with the matrix pipe idle).  Landing is guaranteed by
+    // counted waits: in-order completion, and at least N younger ring pieces issued since (N_* below).
+    constexpr bool PREFB = W >= 256;
+    constexpr int SLABS_FULL = (W / 32) * (W / 16) / MCNX3_SLABF;                       // ring slabs of one W x W segment
+    constexpr int SLABS_ENC = (2 * (W / 16) + MCNX3_SLABF - 1) / MCNX3_SLABF;           // ... of a 2-tile encoded-column segment
+    constexpr int N_IDX = PPW * (2 * SLABS_FULL - 1) < 63 ? PPW * (2 * SLABS_FULL - 1) : 63;      // index pairs: issued >= two W x W segments earlier
+    constexpr int N_TOP = PPW * (SLABS_FULL + SLABS_ENC - 1) < 63 ? PPW * (SLABS_FULL + SLABS_ENC - 1) : 63;   // gathers: >= trunk layer 1 + layer 0's columns earlier
+    const unsigned in_lds = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem) + SM::oIn + wave * (16 * 256);
+    const float* in_rd = reinterpret_cast<const float*>(smem + SM::oIn + wave * (16 * 256)) + lane;
+    auto gather_dma = [&](int ray, int j) {
+        mcn16_dma4(a.zgrid + j, in_lds);
+        if (a.jitter) mcn16_dma4(a.jitter + ray, in_lds + 256);
+        const size_t addr = ((size_t)ray * a.S + j) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            mcn16_dma4(a.out + addr + c, in_lds + (2 + c) * 256);
+            mcn16_dma4(a.d_out + addr + c, in_lds + (6 + c) * 256);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            mcn16_dma4(a.rays_d + ray * 3 + c, in_lds + (10 + c) * 256);
+            mcn16_dma4(a.rays_o + ray * 3 + c, in_lds + (13 + c) * 256);
+        }
+    };
+    auto read_in = [&](int ray) -> In {
+        In r;
+        r.ray = ray;
+        r.zg = in_rd[0];
+        r.jit = a.jitter ? in_rd[64] : 0.f;
+        r.o = f32x4{in_rd[2 * 64], in_rd[3 * 64], in_rd[4 * 64], in_rd[5 * 64]};
+        r.go = f32x4{in_rd[6 * 64], in_rd[7 * 64], in_rd[8 * 64], in_rd[9 * 64]};
+        r.dx = in_rd[10 * 64]; r.dy = in_rd[11 * 64]; r.dz = in_rd[12 * 64];
+        r.ox = in_rd[13 * 64]; r.oy = in_rd[14 * 64]; r.oz = in_rd[15 * 64];
+        return r;
+    };
     In cur;
+    int ray_n = 0;                                              // (wide net) the coming pass's ray of this lane's row
     {
         const long long gc0 = row_of(blockIdx.x);
         int ray0, j0;
         if (a.idx) { const int2 rj = a.idx[gc0]; ray0 = rj.x; j0 = rj.y; }
         else { ray0 = (int)(gc0 / a.S); j0 = (int)(gc0 - (long long)ray0 * a.S); }
-        cur = gather(ray0, j0);
+        if (PREFB) { gather_dma(ray0, j0); ray_n = ray0; }
+        else cur = gather(ray0, j0);
     }
 
     Mcn16Ring ring;
@@ -217,6 +257,10 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         const unsigned* mask_lane = a.mask_ws + ((size_t)tile * 64 + lane) * MW;
         char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)tile * (2 * KS) * 1024 + lane * 16;
         // ---- per-sample prologue (lane-local): sigmoid and SH backward
+        if (PREFB) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_TOP) : "memory");       // (the first pass: vmcnt(0) was waited for below the mask prefetch)
+            cur = read_in(ray_n);
+        }
         const int ray = cur.ray;
         unsigned mk_s[MW], mk_c[MW], mk_t[MW];
         float zv = cur.zg;
@@ -273,6 +317,17 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
             const long long gn = (pass_n * WAVES + wave) * 32 + (lane >> 1);
             mcn16_dma4(reinterpret_cast<const int*>(a.idx) + 2 * (gn < total ? gn : total - 1) + (lane & 1), idx_lds);
         }
+        // (the forward's saved sh.2 outputs for the view-direction term: ordinary loads issued HERE and consumed at the end of the
+        //  pass, behind hundreds of younger operations -- whatever count hipcc waits for there is long satisfied)
+        const bool want_rays = a.d_rays_o || a.d_rays_d;
+        f32x4 shs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) shs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (PREFB && want_rays) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                shs[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 4096 + q * 1024 + lane * 16);
+        }
         u32x4_t xah[KS], xal[KS], xbh[KS], xbl[KS];
         f32x16 denc[2];
 #pragma unroll
@@ -327,11 +382,26 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
                 if (!MASK_DMA) { mask_read(mln, mk0_s, 0, D); mask_read(mln, mk0_c, 1, D + 1); mask_read(mln, mk0_t, 2, D - 1); }
             }
         };
+        auto next_rows = [&]() {     // (wide net) the coming pass's rows: index pair from LDS, gathers by LDS-DMA
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_IDX) : "memory");
+            int rn, jn;
+            if (a.idx) {
+                const int2 rj = *reinterpret_cast<const int2*>(smem + SM::oIdx + wave * 256 + m * 8);
+                rn = rj.x; jn = rj.y;
+            } else {
+                const long long gn = row_of(pass_n);
+                rn = (int)(gn / a.S); jn = (int)(gn - (long long)rn * a.S);
+            }
+            gather_dma(rn, jn);
+            ray_n = rn;
+        };
         for (int l = D - 1; l >= 1; l -= 2) {
+            if (PREFB && l == 1) next_rows();
             trunk_masks(l);
             if (l == skip) mcnx3_bwd_seg<W, KS, 2, 3, PPW>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, nullptr);      // encoded columns of the skip layer
             mcnx3_bwd_seg<W, KS, NT, 1, PPW>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, dy_lane + (size_t)(l - 1) * a.slot_bytes);
             if (l - 1 >= 1) {
+                if (PREFB && l - 1 == 1) next_rows();
                 trunk_masks(l - 1);
                 if (l - 1 == skip) mcnx3_bwd_seg<W, KS, 2, 3, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, nullptr);
                 mcnx3_bwd_seg<W, KS, NT, 1, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, dy_lane + (size_t)(l - 2) * a.slot_bytes);
@@ -341,8 +411,11 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
             }
         }
         // ---- the next pass's rows: index pair from LDS (DMA'd during this pass's prologue), gathers land under the last GEMM and the epilogue
-        In nxt;
-        {
+        In nxt = cur;
+        if (PREFB && D < 2) {        // (no trunk layer to hide the gathers behind: issue them here, drained by the settle below)
+            next_rows();
+        }
+        if (!PREFB) {
             int rn, jn;
             if (a.idx) {
                 const int2 rj = *reinterpret_cast<const int2*>(smem + SM::oIdx + wave * 256 + m * 8);
@@ -353,18 +426,15 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
             }
             nxt = gather(rn, jn);
         }
-        // (the saved sh.2 outputs for the view-direction term are fetched under the last GEMM: the fp32 accumulator tile of the forward)
-        const bool want_rays = a.d_rays_o || a.d_rays_d;
-        f32x4 shs[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) shs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (want_rays) {
+        // (narrow nets: the saved sh.2 outputs for the view-direction term are fetched under the last GEMM)
+        if (!PREFB && want_rays) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 shs[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 4096 + q * 1024 + lane * 16);
         }
         mcnx3_bwd_seg<W, KS, 2, 3, PPW>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, nullptr);       // layer 0: encoded columns
         auto settle = [&]() {
+            if (PREFB && D >= 2) return;     // (wide net: nothing to wait for here -- the gathers are waited for at the top of the coming pass)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(nxt.ray), "+v"(nxt.zg), "+v"(nxt.jit), "+v"(nxt.o), "+v"(nxt.go));
             asm volatile("" : "+v"(nxt.dx), "+v"(nxt.dy), "+v"(nxt.dz), "+v"(nxt.ox), "+v"(nxt.oy), "+v"(nxt.oz));
@@ -452,7 +522,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
             }
         }
         if (!want_rays) settle();
-        cur = nxt;
+        if (!PREFB) cur = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

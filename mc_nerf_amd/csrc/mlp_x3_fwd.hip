@@ -172,6 +172,13 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
     // gathers through them in front of the SH head; explicit counted waits (at most PPW * AHEAD operations are ever younger
     // than something issued a whole layer earlier) guarantee the landing.
     constexpr bool PREF = WAVES == 4;
+    // (counted waits: in-order completion, at least N younger ring pieces issued since the operation waited for -- the index
+    //  pairs: layer 0 + the sigma head; the gathers: the SH head + sh.2 -- and as many as vmcnt can express otherwise, so that the
+    //  workspace stores in flight are not waited for)
+    constexpr int SLABS_FULL = (W / 32) * (W / 16) / MCNX3_SLABF, SLABS_L0 = ((W / 32) * MCN16_ENCKS + MCNX3_SLABF - 1) / MCNX3_SLABF;
+    constexpr int SLABS_SH2 = (W / 16 + MCNX3_SLABF - 1) / MCNX3_SLABF;
+    constexpr int N_IDX = PPW * (SLABS_L0 + SLABS_FULL - 1) < 63 ? PPW * (SLABS_L0 + SLABS_FULL - 1) : 63;
+    constexpr int N_TOP = PPW * (SLABS_FULL + SLABS_SH2 - 1) < 63 ? PPW * (SLABS_FULL + SLABS_SH2 - 1) : 63;
     const unsigned idx_lds = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem) + SM::oIdx + wave * 256;
     const unsigned in_lds = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem) + SM::oIn + wave * (8 * 256);
     const float* in_rd = reinterpret_cast<const float*>(smem + SM::oIn + wave * (8 * 256)) + lane;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         float zv, dx, dy, dz, ox, oy, oz;
         if (PREF) {
             ray = ray_n; j = j_n;
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * MCN16_AHEAD) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_TOP) : "memory");
             zv = in_rd[0];
             if (a.jitter) zv = __fadd_rn(zv, in_rd[64]);
             dx = in_rd[2 * 64]; dy = in_rd[3 * 64]; dz = in_rd[4 * 64];
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         mcnx3_layer<W, SAVE, 0, KS, 1, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + D * W, w2_h, dot,
                                             SAVE ? act_lane + (size_t)D * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)D * a.mask_slot_words : nullptr);
         if (PREF) {                // the coming pass's rows: index pair from LDS, gathers by LDS-DMA (landed long before the pass ends)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * MCN16_AHEAD) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_IDX) : "memory");
             if (a.idx) {
                 const int2 rj = *reinterpret_cast<const int2*>(smem + SM::oIdx + wave * 256 + m * 8);
                 ray_n = rj.x; j_n = rj.y;

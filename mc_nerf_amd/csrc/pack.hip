@@ -2,7 +2,6 @@
 // forward orientation and the transposed one used by dX = W^T dY).  One launch per optimiser step;
 // 2 x 0.63 M floats for the 8x256 net, i.e. microseconds.
 #include "mcnerf_kernels.h"
-#include "mcnerf_h.h"
 
 struct PackSeg {
     int src, ld, col0;       // W[n][k] = params[src + n*ld + col0 + k]
@@ -53,63 +52,8 @@ __global__ void pack_kernel(PackTable t, const float* __restrict__ params, float
     }
 }
 
-// Split-f16 packing (mcnerf_h.h): one thread = one 8-half fragment (hi) and its lo twin.
-//   forward    PH [ntile][ks16][part][lane][8] = S*W[32 ntile + r][16 ks16 + 8 h + j]
-//   transposed PHT[ktile][ns16][part][lane][8] = S*W[16 ns16 + 8 h + j][32 ktile + r]
-// A segment occupies the same byte range as in the fp32 packed buffer (2 halves x 2 parts = 4 bytes per weight).
-__global__ void pack_h_kernel(PackTable t, const float* __restrict__ params, _Float16* __restrict__ packed) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total8 = t.total4 / 2;            // 8-weight fragments per orientation
-    if (gid >= 2 * total8) return;
-    const bool transposed = gid >= total8;
-    const int id8 = transposed ? gid - total8 : gid;
-    int s = 0;
-    while (s + 1 < t.nseg && id8 >= t.seg[s + 1].first4 / 2) ++s;
-    const PackSeg sg = t.seg[s];
-    const int loc = id8 - sg.first4 / 2;        // fragment index inside the segment: (tile, step, lane)
-    const int lane = loc & 63;
-    const int blk = loc >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    h8 hi, lo;
-    if (!transposed) {
-        const int KS = sg.k_pad / 16;
-        const int ntile = blk / KS, ks = blk - ntile * KS;
-        const int n = 32 * ntile + r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 16 * ks + 8 * h + j;
-            const float w = (n < sg.n_real && k < sg.k_real) ? params[sg.src + n * sg.ld + sg.col0 + k] * MCN_SW : 0.f;
-            _Float16 a, b; mcn_split(w, a, b); hi[j] = a; lo[j] = b;
-        }
-        _Float16* dst = packed + 2 * (size_t)sg.dst_f + ((size_t)blk * 2) * 512 + lane * 8;
-        *reinterpret_cast<h8*>(dst) = hi;
-        *reinterpret_cast<h8*>(dst + 512) = lo;
-    } else {
-        const int NS = sg.n_pad / 16;
-        const int ktile = blk / NS, ns = blk - ktile * NS;
-        const int k = 32 * ktile + r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int n = 16 * ns + 8 * h + j;
-            const float w = (n < sg.n_real && k < sg.k_real) ? params[sg.src + n * sg.ld + sg.col0 + k] * MCN_SW : 0.f;
-            _Float16 a, b; mcn_split(w, a, b); hi[j] = a; lo[j] = b;
-        }
-        _Float16* dst = packed + 2 * (size_t)sg.dst_b + ((size_t)blk * 2) * 512 + lane * 8;
-        *reinterpret_cast<h8*>(dst) = hi;
-        *reinterpret_cast<h8*>(dst + 512) = lo;
-    }
-}
 
 static void build_pack_table(const McnLayout& L, PackTable& t);
-
-hipError_t mcn_launch_pack_h(const McnLayout& L, const float* params, void* packed, hipStream_t st) {
-    PackTable t;
-    build_pack_table(L, t);
-    const int threads = 256;
-    const int grid = (2 * (t.total4 / 2) + threads - 1) / threads;
-    hipLaunchKernelGGL(pack_h_kernel, dim3(grid), dim3(threads), 0, st, t, params, reinterpret_cast<_Float16*>(packed));
-    return hipGetLastError();
-}
 
 hipError_t mcn_launch_pack(const McnLayout& L, const float* params, float* packed, hipStream_t st) {
     PackTable t;

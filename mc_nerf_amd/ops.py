@@ -99,9 +99,9 @@ def flatten_params(net: Net, tensors, device) -> Tensor:
 
 
 # --------------------------------------------------------------------------- ops
-PRECISIONS = ("f32", "f16x3", "f16", "bf16", "f16x3r1")
+PRECISIONS = ("f32", "f16x3", "f16", "bf16")
 # register-chain modes: single-pass 16-bit MFMA (csrc/mcnerf_16.h) and split-f16 "f16x3" (csrc/mcnerf_x3.h): name -> dtype
-# code of the C ABI.  ("f16x3r1" = the round-1 split-f16 kernels, kept for A/B measurements only)
+# code of the C ABI
 DTYPE16 = {"f16": 0, "bf16": 1, "f16x3": 2}
 
 
@@ -130,8 +130,7 @@ def pack_weights(net: Net, params: Tensor, packed=None, precision: str = "f32"):
         return packed
     if packed is None:
         packed = torch.empty(packed_count(net), dtype=torch.float32, device=params.device)
-    name = "mcnerf_pack_weights" if precision == "f32" else "mcnerf_pack_weights_f16x3"      # ("f16x3r1")
-    _lib.call(name, *net.triple, _p(params), _p(packed), _stream())
+    _lib.call("mcnerf_pack_weights", *net.triple, _p(params), _p(packed), _stream())
     return packed
 
 
@@ -194,7 +193,7 @@ def mlp_fwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
                   _p(save.enc, torch.uint8) if save else None, _p(save.mask, torch.int32) if save else None,
                   _p(save.sh, torch.uint8) if save else None, _stream())
         return
-    _lib.call("mcnerf_mlp_fwd" if precision == "f32" else "mcnerf_mlp_fwd_f16x3", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
+    _lib.call("mcnerf_mlp_fwd", *net.triple, _p(params), _p(packed), _p(rays_o), _p(rays_d), _p(zgrid),
               _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
               _p(out), _p(save.act) if save else None, save.capacity if save else 0,
               _p(save.enc) if save else None, _p(save.sh) if save else None,
@@ -253,10 +252,7 @@ def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
             _p(jitter), _p(barf_w), _p(idx, torch.int32), _p(count, torch.int32), int(max_rows), n_rays, S,
             _p(out), _p(d_out), _p(save.mask, torch.int32), save.capacity, _p(save.enc), _p(save.sh),
             _p(dy), _p(dsh), _p(d_rays_o), _p(d_rays_d)]
-    if precision == "f32":
-        _lib.call("mcnerf_mlp_bwd", *args, _stream())
-    else:
-        _lib.call("mcnerf_mlp_bwd_f16x3", *args, _p(gmax, torch.int32), _stream())
+    _lib.call("mcnerf_mlp_bwd", *args, _stream())
 
 
 def mlp_dw(net: Net, save: MlpSave, dy: Tensor, dsh: Tensor, grads: Tensor, rows: int,
@@ -267,10 +263,7 @@ def mlp_dw(net: Net, save: MlpSave, dy: Tensor, dsh: Tensor, grads: Tensor, rows
                   _p(gmax, torch.int32), _stream())
         return
     args = [*net.triple, _p(count, torch.int32), int(rows), _p(save.act), _p(save.enc), _p(dy), _p(dsh), save.capacity, _p(grads)]
-    if precision == "f32":
-        _lib.call("mcnerf_mlp_dw", *args, _stream())
-    else:
-        _lib.call("mcnerf_mlp_dw_f16x3", *args, _p(gmax, torch.int32), _stream())
+    _lib.call("mcnerf_mlp_dw", *args, _stream())
 
 
 def composite_fwd(sig_rgb: Tensor, rays_d: Tensor, zgrid: Tensor, jitter: Optional[Tensor], eps: Tensor,
@@ -453,7 +446,7 @@ def decode_masks_16(mask: Tensor, n_slots: int, width: int, rows: int) -> Tensor
     return out.reshape(n_slots, tiles * 32, width)[:, :rows]
 
 
-SPLIT_SCALE_X = 8.0      # MCN_SX of csrc/mcnerf_h.h = MCNX3_SX of csrc/mcnerf_x3.h
+SPLIT_SCALE_X = 8.0      # MCNX3_SX of csrc/mcnerf_x3.h
 
 
 def decode_sh_x3(buf: Tensor, rows: int) -> Tensor:
@@ -461,12 +454,3 @@ def decode_sh_x3(buf: Tensor, rows: int) -> Tensor:
     register 4 q + e of lane (m, h) is SH row 8 q + 4 h + e.  Debug / test helper."""
     x = buf.view(torch.float32).view(-1, 4, 2, 32, 4)            # [tile][q][h][m][e]
     return x.permute(0, 3, 1, 2, 4).reshape(-1, 32)[:rows]       # [tile, m][q, h, e] -> row 8 q + 4 h + e
-
-
-def decode_split_words(t: Tensor, scale: float = SPLIT_SCALE_X) -> Tensor:
-    """Workspaces written by the f16x3 kernels hold one `hi | lo << 16` word per value (mcnerf_h.h); this returns
-    the fp32 values (hi + lo) / scale.  Debug / test helper: the kernels consume the words directly."""
-    w = t.view(torch.int32)
-    hi = (w & 0xFFFF).to(torch.int16).view(torch.float16).float()
-    lo = ((w >> 16) & 0xFFFF).to(torch.int16).view(torch.float16).float()
-    return (hi + lo) / scale
