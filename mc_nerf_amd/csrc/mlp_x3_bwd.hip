@@ -96,7 +96,7 @@ __device__ __forceinline__ void mcnx3_bwd_seg(Mcn16Ring& ring, char* smem, int l
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const int f = t * KSTEPS + s;
-            mcnx3_before_mfma<F, PPW>(ring, cur, f);
+            mcnx3_before_mfma_spread<F, PPW>(ring, cur, f);
             const u32x4_t a_h = afh[f % MCNX3_PF], a_l = afl[f % MCNX3_PF];
             if (f + MCNX3_PF < F) {
                 const unsigned o = mcnx3_frag_off(ring, cur, f, f + MCNX3_PF) + lane * 16;
@@ -116,6 +116,7 @@ __device__ __forceinline__ void mcnx3_bwd_seg(Mcn16Ring& ring, char* smem, int l
                     for (int q = 0; q < 4; ++q)
                         if (INIT_N == 1 || q == gap - INIT_G) acc_init(acc[(t + 1) & 1], t + 1, q);
                 }
+                mcnx3_gap_dma<F, PPW>(ring, 3 * f + g);
                 __builtin_amdgcn_sched_barrier(0);
                 if (EPI) acc[t & 1] = mcnx3_mfma(g == 0 ? a_l : a_h, g == 1 ? inl[s] : inh[s], acc[t & 1]);
                 else acc2[t & 1] = mcnx3_mfma(g == 0 ? a_l : a_h, g == 1 ? inl[s] : inh[s], acc2[t & 1]);
@@ -123,6 +124,7 @@ __device__ __forceinline__ void mcnx3_bwd_seg(Mcn16Ring& ring, char* smem, int l
             }
         }
     }
+    mcnx3_layer_end<F, PPW>(ring);
     if (EPI) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) item(acc[(NTILES - 1) & 1], NTILES - 1, i);

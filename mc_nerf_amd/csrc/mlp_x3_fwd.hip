@@ -103,7 +103,7 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
 #pragma unroll
         for (int s = 0; s < KTOT; ++s) {
             const int f = t * KTOT + s;
-            mcnx3_before_mfma<F, PPW>(ring, cur, f);
+            mcnx3_before_mfma_spread<F, PPW>(ring, cur, f);
             const u32x4_t a_h = afh[f % MCNX3_PF], a_l = afl[f % MCNX3_PF];
             if (f + MCNX3_PF < F) {
                 const unsigned o = mcnx3_frag_off(ring, cur, f, f + MCNX3_PF) + lane * 16;
@@ -121,12 +121,14 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
                         if (i < NIT) item(acc[(t - 1) & 1], t - 1, i);
                 }
                 if (gap == BIAS_G && t + 1 < NT) bias_init(acc[(t + 1) & 1], t + 1);
+                mcnx3_gap_dma<F, PPW>(ring, 3 * f + g);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[t & 1] = mcnx3_mfma(g == 0 ? a_l : a_h, g == 1 ? b_l : b_h, acc[t & 1]);     // lo*hi, hi*lo, hi*hi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
+    mcnx3_layer_end<F, PPW>(ring);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) item(acc[(NT - 1) & 1], NT - 1, i);
     if (SAVE) {
