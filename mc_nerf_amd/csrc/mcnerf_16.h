@@ -239,6 +239,7 @@ struct Mcn16Ring {
     unsigned issue_slot;      // ring slot (0..RING-1) of the next issue
     unsigned sync_slot;       // ring slot of the next slab to synchronise
     unsigned next_off;        // LDS byte offset of the slab synchronised last (the one after the slab being consumed)
+    const char* piece_src;    // (mcnerf_x3.h, spread refill) this lane's source address of piece 0 of the slab being refilled
 #ifdef ABL16_NORING
     bool first_fill;
 #endif

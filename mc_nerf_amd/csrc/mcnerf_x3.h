@@ -139,27 +139,31 @@ __device__ __forceinline__ void mcnx3_before_mfma(Mcn16Ring& r, Mcn16Cursor& c, 
 #ifndef MCNX3_DMA_STEP
 #define MCNX3_DMA_STEP 2
 #endif
-__device__ __forceinline__ void mcnx3_ring_sync_only(Mcn16Ring& r, int ppw_ahead) {
-    r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
-    r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
-    (void)ppw_ahead;
-}
+// The refill's addresses are set up ONCE per slab at the synchronisation point -- the lane's source address in a register pair,
+// the LDS destination in M0 (nothing else in these kernels uses M0; the other LDS-DMA helpers save and restore it) -- and
+// every piece is then a single instruction: the instruction's immediate offset advances both the global and the LDS address,
+// and a slab's pieces are 1 KiB apart in both.
 template <int PPW>
-__device__ __forceinline__ void mcnx3_ring_piece(Mcn16Ring& r, int i) {         // piece i of the slab being issued; the last one advances the cursor
-    const char* s = r.src + (size_t)r.src_slab * (MCN16_SLAB * 1024);
-    const unsigned d = r.lds_base + r.issue_slot * (MCN16_SLAB * 1024) + r.lds_piece;
-    mcn16_dma16(s + i * 1024, d + i * 1024);
-    if (i == PPW - 1) {
-        r.src_slab = (r.src_slab + 1 == r.n_slabs) ? 0 : r.src_slab + 1;
-        r.issue_slot = (r.issue_slot + 1) & (MCN16_RING - 1);
+__device__ __forceinline__ void mcnx3_ring_piece(Mcn16Ring& r, int i) {
+    switch (i) {              // (immediate offsets)
+        case 0: asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(r.piece_src) : "memory"); break;
+        case 1: asm volatile("global_load_lds_dwordx4 %0, off offset:1024" ::"v"(r.piece_src) : "memory"); break;
+        case 2: asm volatile("global_load_lds_dwordx4 %0, off offset:2048" ::"v"(r.piece_src) : "memory"); break;
+        default: asm volatile("global_load_lds_dwordx4 %0, off offset:3072" ::"v"(r.piece_src) : "memory"); break;
     }
 }
 template <int F, int PPW>
 __device__ __forceinline__ void mcnx3_before_mfma_spread(Mcn16Ring& r, Mcn16Cursor& c, int f) {
+    static_assert(PPW <= 4, "immediate offsets of the refill pieces");
     if ((f & (MCNX3_SLABF - 1)) == 0) c.cur = r.next_off;
     if (f == mcnx3_sync_at<F>(f / MCNX3_SLABF)) {
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW * (MCN16_AHEAD - 1)) : "memory");
-        mcnx3_ring_sync_only(r, 0);
+        r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
+        r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
+        r.piece_src = r.src + (size_t)r.src_slab * (MCN16_SLAB * 1024);
+        asm volatile("s_mov_b32 m0, %0" ::"s"(r.lds_base + r.issue_slot * (MCN16_SLAB * 1024) + r.lds_piece) : "memory");
+        r.src_slab = (r.src_slab + 1 == r.n_slabs) ? 0 : r.src_slab + 1;
+        r.issue_slot = (r.issue_slot + 1) & (MCN16_RING - 1);
     }
 }
 // called in every MFMA gap `gap` (= 3 f + g) of a layer: at most one piece
