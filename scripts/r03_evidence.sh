@@ -16,3 +16,15 @@ mkdir -p gpurun_out/sq_$TAG
 scripts/pmc_sq.sh $TAG f16x3 25600 256 > /dev/null 2>&1
 python3 scripts/pmc_sq_summary.py gpurun_out/sq_$TAG > gpurun_out/${TAG}_sq_counters_f16x3.txt 2>&1
 ls -la gpurun_out | tail -20
+# ---- the other workload shapes of BASELINE.json / DESIGN.md 5 (headline mode unless said otherwise), one JSON line each
+B="python3 bench.py --also= --no-cpu-baseline --steps 20 --warmup 3"
+for RIG in array halfball room; do $B --rig $RIG 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_rig_$RIG.json; done
+$B --rays 7000 --steps 50 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_7k.json
+$B --rays 7000 --steps 50 --samples 128 --scale 5 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_7k_128x5.json
+$B --rig room --img 1600 --samples 64 --scale 4 --precision bf16 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_cfg5_bf16.json
+$B --rig room --img 1600 --samples 64 --scale 4 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_cfg5_f16x3.json
+python3 bench.py --mode render --steps 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_render_f16x3.json
+python3 bench.py --mode render --steps 3 --precision f16 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_render_f16.json
+scripts/probe/mfma_peak > gpurun_out/${TAG}_mfma_peak.txt 2>&1
+python3 scripts/sparsity_probe.py 2>/dev/null > gpurun_out/${TAG}_sparsity.txt
+ls gpurun_out | grep ${TAG}_
