@@ -575,3 +575,38 @@ def test_fused_train_loss_matches_eager_formulation(gpu_device, normalise, with_
     for a, b in zip(got, [pd.grad, rc.grad, rf.grad if with_fine else None]):
         if b is not None:
             assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12
+
+
+def test_fused_radam_guard_refuses_the_whole_step(gpu_device):
+    """An optimiser step that spans several fused launches -- two param groups (the NeRF nets and the cameras), tensors with
+    different step counts, more than 64 tensors -- is refused AS A WHOLE: a non-finite gradient in the LAST launch's tensors leaves
+    the first launch's parameters and moments untouched too, and the refused step is counted once (not once per launch)."""
+    from mc_nerf_amd.model import RAdam
+    dev = gpu_device
+    g = torch.Generator().manual_seed(5)
+    many = [torch.nn.Parameter(torch.randn(37, generator=g).to(dev)) for _ in range(70)]        # > 64 tensors: two chunks of one call
+    cams = [torch.nn.Parameter(torch.randn(110, 6, generator=g).to(dev)), torch.nn.Parameter(torch.randn(110, generator=g).to(dev))]
+    opt = RAdam([{"params": many}, {"params": cams, "lr": 1e-3}], lr=1e-2, weight_decay=1e-3)
+
+    def grads(skip=None):
+        for i, p in enumerate(many + cams):
+            p.grad = None if i == skip else torch.randn_like(p)
+    grads(skip=3)
+    opt.step()                                        # tensor 3 sits out one step: its step count differs from now on (its own launch)
+    grads()
+    opt.step()
+    before = [p.detach().clone() for p in many + cams]
+    m_before = [opt.state[p]["exp_avg"].clone() for p in many + cams]
+    grads()
+    cams[1].grad[17] = float("nan")                   # the last tensor of the last group
+    opt.step()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, many + cams))
+    assert all(torch.equal(a, opt.state[p]["exp_avg"]) for a, p in zip(m_before, many + cams))
+    assert opt.skipped_steps() == 1
+    grads()
+    many[68].grad[0] = float("inf")                   # in the second chunk of the first group: the first chunk must not have moved
+    opt.step()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, many + cams)) and opt.skipped_steps() == 2
+    grads()
+    opt.step()                                        # finite again
+    assert all(not torch.equal(a, p.detach()) for a, p in zip(before, many + cams)) and opt.skipped_steps() == 2
