@@ -145,6 +145,9 @@ __device__ __forceinline__ void mcnx3_before_mfma(Mcn16Ring& r, Mcn16Cursor& c, 
 // and a slab's pieces are 1 KiB apart in both.
 template <int PPW>
 __device__ __forceinline__ void mcnx3_ring_piece(Mcn16Ring& r, int i) {
+#ifdef ABLX3_NODMA            // (timing-only: the ring is never refilled)
+    return;
+#endif
     switch (i) {              // (immediate offsets)
         case 0: asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(r.piece_src) : "memory"); break;
         case 1: asm volatile("global_load_lds_dwordx4 %0, off offset:1024" ::"v"(r.piece_src) : "memory"); break;
@@ -157,7 +160,9 @@ __device__ __forceinline__ void mcnx3_before_mfma_spread(Mcn16Ring& r, Mcn16Curs
     static_assert(PPW <= 4, "immediate offsets of the refill pieces");
     if ((f & (MCNX3_SLABF - 1)) == 0) c.cur = r.next_off;
     if (f == mcnx3_sync_at<F>(f / MCNX3_SLABF)) {
+#ifndef ABLX3_NOSYNC          // (timing-only: no wait, no barrier at the slab boundaries)
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW * (MCN16_AHEAD - 1)) : "memory");
+#endif
         r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
         r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
         r.piece_src = r.src + (size_t)r.src_slab * (MCN16_SLAB * 1024);

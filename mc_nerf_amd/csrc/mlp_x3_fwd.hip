@@ -105,21 +105,25 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
             const int f = t * KTOT + s;
             mcnx3_before_mfma_spread<F, PPW>(ring, cur, f);
             const u32x4_t a_h = afh[f % MCNX3_PF], a_l = afl[f % MCNX3_PF];
+#ifndef ABLX3_NOLDS        // (timing-only: the A pieces are not re-read)
             if (f + MCNX3_PF < F) {
                 const unsigned o = mcnx3_frag_off(ring, cur, f, f + MCNX3_PF) + lane * 16;
                 afh[f % MCNX3_PF] = *reinterpret_cast<const u32x4_t*>(smem + o);
                 afl[f % MCNX3_PF] = *reinterpret_cast<const u32x4_t*>(smem + o + 1024);
             }
+#endif
             const u32x4_t b_h = s < KENC ? ench[s < KENC ? s : 0] : inh[s >= KENC ? s - KENC : 0];
             const u32x4_t b_l = s < KENC ? encl[s < KENC ? s : 0] : inl[s >= KENC ? s - KENC : 0];
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const int gap = 3 * s + g;
+#ifndef ABLX3_NOEPI        // (timing-only ablations, scripts/time_kernels.py: no epilogue work in the MFMA gaps)
                 if (t > 0 && gap >= START) {
 #pragma unroll
                     for (int i = (gap - START) * IPG; i < (gap - START + 1) * IPG; ++i)
                         if (i < NIT) item(acc[(t - 1) & 1], t - 1, i);
                 }
+#endif
                 if (gap == BIAS_G && t + 1 < NT) bias_init(acc[(t + 1) & 1], t + 1);
                 mcnx3_gap_dma<F, PPW>(ring, 3 * f + g);
                 __builtin_amdgcn_sched_barrier(0);
@@ -136,6 +140,17 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
         for (int i = 0; i < MW; ++i) mcn16_ws_store(mw[i], mask_lane + i);
     }
 }
+
+#ifdef MCNX3_STAMPS     // (diagnostic build: in-kernel cycle stamps of the pass phases, read back by scripts/stamps_x3.py)
+__device__ unsigned long long g_mcnx3_fstamps[2 * 64 * 16];
+extern "C" int mcnerf_debug_stamps_x3_fwd(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mcnx3_fstamps), sizeof(g_mcnx3_fstamps));
+}
+#define MCNX3_FSTAMP(i) do { if (W == 256 && blockIdx.x < 64 && pass == (long long)blockIdx.x + 20ll * gridDim.x && lane == 0 && wave == 0) \
+        g_mcnx3_fstamps[((SAVE ? 64 : 0) + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MCNX3_FSTAMP(i) do { } while (0)
+#endif
 
 template <int W, bool SAVE>
 __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x3_fwd_kernel(Mcn16FwdArgs a) {
@@ -220,6 +235,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         const bool valid = g < total;
         const long long gc = valid ? g : total - 1;
         const long long pass_n = pass + gridDim.x;
+        MCNX3_FSTAMP(0);
         // ---- per-sample setup (lane-local; both lane halves of a sample compute the same values)
         int ray, j;
         float zv, dx, dy, dz, ox, oy, oz;
@@ -276,17 +292,21 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         float dot = 0.f;
         // ---- layer 0 (encoded input only), then the trunk two layers per trip (xb -> xa -> xb: no copies between layers);
         //      the skip layer takes [encoding, hidden]
+        MCNX3_FSTAMP(1);
         mcnx3_layer<W, SAVE, MCN16_ENCKS, 0, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h, nullptr, dot, act_lane, mask_lane);
+        MCNX3_FSTAMP(2);
         for (int l = 1; l < D; l += 2) {
             char* sl = SAVE ? act_lane + (size_t)l * a.slot_bytes : nullptr;
             unsigned* ml = SAVE ? mask_lane + (size_t)l * a.mask_slot_words : nullptr;
             if (l == skip) mcnx3_layer<W, SAVE, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + l * W, nullptr, dot, sl, ml);
             else mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + l * W, nullptr, dot, sl, ml);
+            MCNX3_FSTAMP(2 + l);
             if (l + 1 < D) {
                 sl = SAVE ? act_lane + (size_t)(l + 1) * a.slot_bytes : nullptr;
                 ml = SAVE ? mask_lane + (size_t)(l + 1) * a.mask_slot_words : nullptr;
                 if (l + 1 == skip) mcnx3_layer<W, SAVE, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + (l + 1) * W, nullptr, dot, sl, ml);
                 else mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + (l + 1) * W, nullptr, dot, sl, ml);
+                MCNX3_FSTAMP(3 + l);
             } else {               // an even trunk depth ends in xa: one copy per pass
 #pragma unroll
                 for (int s = 0; s < KS; ++s) { xbh[s] = xah[s]; xbl[s] = xal[s]; }
@@ -295,6 +315,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         // ---- sigma head: hidden layer on the matrix pipe, the 1-wide output layer lane-local (on the fp32 activations)
         mcnx3_layer<W, SAVE, 0, KS, 1, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + D * W, w2_h, dot,
                                             SAVE ? act_lane + (size_t)D * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)D * a.mask_slot_words : nullptr);
+        MCNX3_FSTAMP(10);
         if (PREF) {                // the coming pass's rows: index pair from LDS, gathers by LDS-DMA (landed long before the pass ends)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_IDX) : "memory");
             if (a.idx) {
@@ -309,6 +330,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         // ---- SH head: hidden layer (reads the same trunk output), then the 27 (32) coefficient rows
         mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + (D + 1) * W, nullptr, dot,
                                             SAVE ? act_lane + (size_t)(D + 1) * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)(D + 1) * a.mask_slot_words : nullptr);
+        MCNX3_FSTAMP(11);
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -327,6 +349,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
                 mcnx3_mfma3(acc, a_h, a_l, xah[s], xal[s]);
             }
         }
+        MCNX3_FSTAMP(12);
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] *= 1.0f / SXW;
         if (SAVE) {          // the SH coefficients (bias included) for the backward's view-direction term: the fp32 accumulator tile
@@ -363,6 +386,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
             o[1 + c] = 1.0f / (1.0f + expf(-pc));
         }
         if (valid && h == 0) *reinterpret_cast<f32x4*>(a.out + (size_t)addr * 4) = o;
+        MCNX3_FSTAMP(13);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ring pieces still in flight must land before the LDS is released
 }
