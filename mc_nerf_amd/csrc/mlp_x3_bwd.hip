@@ -10,6 +10,7 @@
 // mlp_x3_dw.hip), scaled by the per-launch power of two SG (f16 range; derived from max|d_out|).
 // Replaces autograd through model/net_block.py:22-33, 67-78 and model/mc_nerf.py:602, 635, 690-691.
 #include "mcnerf_x3.h"
+#include <cstdlib>
 
 template <int W>
 struct BwdX3Smem {
@@ -538,7 +539,10 @@ static hipError_t launch_bwd_x3(const Mcn16BwdArgs& a, long long max_rows, hipSt
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     long long passes = (max_rows + ROWS - 1) / ROWS;
     if (passes <= 0) return hipSuccess;
-    const int grid = (int)(passes < cus ? passes : cus);
+    int grid = (int)(passes < cus ? passes : cus);
+#ifdef MCNERF_EXPERIMENTS      // (scripts/experiments/overlap_probe.py: a grid cap read per launch; not in the product build)
+    if (const char* e = getenv("MCNERF_EXP_CHAIN_GRID")) { int g = atoi(e); if (g > 0 && g < grid) grid = g; }
+#endif
     void (*kern)(Mcn16BwdArgs) = mlp_x3_bwd_kernel<W>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::total);
     if (e != hipSuccess) return e;

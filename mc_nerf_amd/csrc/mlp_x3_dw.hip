@@ -10,6 +10,7 @@
 // piece leaves a segment).  A tile is now 2 (N + K) / 16 pieces of 1 KiB, which leaves room for only 2 tile slots in the
 // CU's 160 KiB at 256 x 256 -- so the slots are filled, consumed and freed by QUARTERS (dwx3_run).
 #include "mcnerf_x3.h"
+#include <cstdlib>
 
 struct DwX3Seg {
     const char* dY; int ksn;      // fragment-major [tile][part][ksn][64][8]: N = 16 ksn columns
@@ -300,6 +301,9 @@ static hipError_t dwx3_launch_job(const DwX3Job& job, const int* count, int rows
     const long long ntiles = (rows_cap + 31) / 32;
     long long grid = dwx3_num_cus();
     if (grid > ntiles * job.n) grid = ntiles * job.n;
+#ifdef MCNERF_EXPERIMENTS      // (scripts/experiments/overlap_probe.py: a grid cap read per launch; not in the product build)
+    if (const char* e = getenv("MCNERF_EXP_DW_GRID")) { long long g = atoll(e); if (g > 0 && g < grid) grid = g; }
+#endif
     // LDS: the largest stages x stage product over the shapes of this width
     constexpr int KS = W / 16;
     constexpr int p0 = 2 * (2 * KS), p1 = 2 * (KS + MCN16_ENCKS), p2 = 2 * (2 + KS), p3 = 2 * (2 * KS + MCN16_ENCKS);
