@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MCNERF_ABI_VERSION 3
+#define MCNERF_ABI_VERSION 4
 
 int mcnerf_abi_version(void);
 const char* mcnerf_last_error(void);
@@ -90,6 +90,22 @@ int mcnerf_encode(const float* x, const float* barf_w, int n, float* out, void* 
 int mcnerf_upload_f32(float* dst, const float* host_vals, int n, void* stream);
 int mcnerf_mlp_apply(int depth, int width, int skip, const float* params, const float* packed, const float* x_enc,
                      const float* dirs, int n, float* out, void* stream);
+
+/* The same two modules DIFFERENTIATED (both are autograd-differentiable in the reference; the host classes wrap these in
+ * torch.autograd.Functions, model/net_block.py):
+ *   mcnerf_encode_bwd:     d_out [n,63] -> d_x [n,3] (written);
+ *   mcnerf_mlp_apply_save: mcnerf_mlp_apply that also fills the exact-fp32 workspaces of mcnerf_mlp_fwd (capacity >= n);
+ *   mcnerf_mlp_apply_bwd:  d_out [n,4] -> d_x_enc [n,63] (written), d_dirs [n,3] (ACCUMULATED: zero it first; the SH view-direction
+ *                          term) and dy_save / dsh_save, from which mcnerf_mlp_dw reduces the parameter gradients as for the
+ *                          render path.  `zero` is a device float holding 0 (the sample depth of the degenerate one-sample ray). */
+int mcnerf_encode_bwd(const float* x, const float* barf_w, int n, const float* d_out, float* d_x, void* stream);
+int mcnerf_mlp_apply_save(int depth, int width, int skip, const float* params, const float* packed, const float* x_enc,
+                          const float* dirs, int n, float* out, float* act_save, long long capacity, float* enc_save,
+                          float* sh_save, uint32_t* mask_save, void* stream);
+int mcnerf_mlp_apply_bwd(int depth, int width, int skip, const float* params, const float* packed, const float* dirs, const float* zero,
+                         int n, const float* out, const float* d_out, const uint32_t* mask_save, long long capacity,
+                         const float* enc_save, const float* sh_save, float* dy_save, float* dsh_save,
+                         float* d_x_enc, float* d_dirs, void* stream);
 
 /* Backward of mcnerf_mlp_fwd wrt the activations (the dX chain): consumes d_out [n_rays,S,4],
  * writes the pre-activation gradients of every layer to dy_save ((depth+2)*capacity*width floats) and

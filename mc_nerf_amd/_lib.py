@@ -15,7 +15,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MCNERF_LIB selects another build of the SAME library (kernel ablation / tuning variants, scripts/ablate.sh)
 LIB_PATH = os.environ.get("MCNERF_LIB") or os.path.join(_HERE, "libmcnerf.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P = c_void_p
 _I = c_int
@@ -39,6 +39,9 @@ SIGNATURES = {
     "mcnerf_scale3": (_I, [_P, _I, _P, _I, _P, _I, _P, _P]),
     "mcnerf_sample_perm": (_I, [_P, ctypes.c_longlong, _I, _P, _P]),
     "mcnerf_mlp_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "mcnerf_encode_bwd": (_I, [_P, _P, _I, _P, _P, _P]),
+    "mcnerf_mlp_apply_save": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _P, _P]),
+    "mcnerf_mlp_apply_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
     "mcnerf_mlp_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,
                             _P, _P, _P, _P, _P]),
     "mcnerf_mlp_dw": (_I, [_I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P]),

@@ -132,6 +132,40 @@ int mcnerf_mlp_apply(int depth, int width, int skip, const float* params, const 
     return check("mcnerf_mlp_apply", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
 }
 
+int mcnerf_encode_bwd(const float* x, const float* barf_w, int n, const float* d_out, float* d_x, void* stream) {
+    REQ(x && barf_w && d_out && d_x && n >= 0, "mcnerf_encode_bwd");
+    return check("mcnerf_encode_bwd", mcn_launch_encode_bwd(x, barf_w, n, d_out, d_x, (hipStream_t)stream));
+}
+// CorseFine_NeRF.forward with the operands of its backward saved (exact-fp32 workspaces, as mcnerf_mlp_fwd's), and that backward
+int mcnerf_mlp_apply_save(int depth, int width, int skip, const float* params, const float* packed, const float* x_enc,
+                          const float* dirs, int n, float* out, float* act_save, long long capacity, float* enc_save,
+                          float* sh_save, uint32_t* mask_save, void* stream) {
+    REQ(net_ok(depth, width, skip) && params && packed && x_enc && dirs && out && n >= 0, "mcnerf_mlp_apply_save");
+    REQ(act_save && enc_save && sh_save && mask_save && capacity >= n, "mcnerf_mlp_apply_save");
+    McnMlpFwdArgs a;
+    a.lay = mcn_make_layout(depth, width, skip);
+    a.params = params; a.packed = packed; a.rays_o = dirs; a.rays_d = dirs; a.zgrid = dirs; a.jitter = nullptr;
+    a.barf_w = dirs; a.idx = nullptr; a.count = nullptr; a.max_rows = 0; a.n_rays = n; a.S = 1;
+    a.out = out; a.act_save = act_save; a.act_stride = MCN_ACT_STRIDE(capacity, width); a.enc_save = enc_save; a.sh_save = sh_save; a.mask_save = mask_save;
+    a.enc_in = x_enc;
+    return check("mcnerf_mlp_apply_save", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
+}
+int mcnerf_mlp_apply_bwd(int depth, int width, int skip, const float* params, const float* packed, const float* dirs, const float* zero,
+                         int n, const float* out, const float* d_out, const uint32_t* mask_save, long long capacity,
+                         const float* enc_save, const float* sh_save, float* dy_save, float* dsh_save,
+                         float* d_x_enc, float* d_dirs, void* stream) {
+    REQ(net_ok(depth, width, skip) && params && packed && dirs && zero && out && d_out && n >= 0, "mcnerf_mlp_apply_bwd");
+    REQ(mask_save && enc_save && sh_save && dy_save && dsh_save && d_x_enc && d_dirs && capacity >= n, "mcnerf_mlp_apply_bwd");
+    McnMlpBwdArgs a;
+    a.lay = mcn_make_layout(depth, width, skip);
+    a.params = params; a.packed = packed; a.rays_o = dirs; a.rays_d = dirs; a.zgrid = zero; a.jitter = nullptr;      // one sample per "ray" at z = 0
+    a.barf_w = dirs; a.idx = nullptr; a.count = nullptr; a.max_rows = 0; a.n_rays = n; a.S = 1;
+    a.out = out; a.d_out = d_out; a.mask_save = mask_save; a.act_stride = MCN_ACT_STRIDE(capacity, width);
+    a.enc_save = enc_save; a.sh_save = sh_save; a.dy_save = dy_save; a.dsh_save = dsh_save;
+    a.d_rays_o = nullptr; a.d_rays_d = d_dirs; a.gmax_bits = nullptr; a.d_enc_out = d_x_enc;
+    return check("mcnerf_mlp_apply_bwd", mcn_launch_mlp_bwd(a, (hipStream_t)stream));
+}
+
 
 int mcnerf_mlp_bwd(int depth, int width, int skip, const float* params, const float* packed,
                    const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,

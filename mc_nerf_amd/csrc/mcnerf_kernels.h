@@ -24,6 +24,7 @@ struct McnMlpFwdArgs {
     const float* enc_in = nullptr;   // fp32 kernel only: caller-supplied encodings [rows][63] instead of the fused positional encoding
 };
 hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, float* out, hipStream_t st);
+hipError_t mcn_launch_encode_bwd(const float* x, const float* barf_w, int n, const float* d_out, float* d_x, hipStream_t st);
 hipError_t mcn_launch_sample_perm(long long* out, long long n, int batch, const unsigned* seed, hipStream_t st);
 hipError_t mcn_launch_train_loss(const float* pd, const float* ptg, int np, int H, int W, int normalise, const float* rgb_c, const float* rgb_f,
                                  const float* gt, int nrgb, float* out, float* d_pd, float* d_c, float* d_f, hipStream_t st);
@@ -56,6 +57,8 @@ struct McnMlpBwdArgs {
     float* d_rays_o;          // [n_rays,3] accumulated with atomics (may be null)
     float* d_rays_d;          // [n_rays,3]
     const unsigned int* gmax_bits;   // split-f16 mode only: float bits of max|d_out| over the launch (device scalar)
+    float* d_enc_out = nullptr;      // stand-alone CorseFine_NeRF backward: the encoded-input gradient [rows][63] is the result
+                                     // (no positional-encoding backward; d_rays_d then receives the SH view-direction term alone)
 };
 hipError_t mcn_launch_mlp_bwd(const McnMlpBwdArgs& a, hipStream_t st);
 

@@ -222,6 +222,12 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
         }
     }
     __syncthreads();
+    if (a.d_enc_out) {     // caller-supplied encodings (model/net_block.py:67-78 differentiated with respect to its input x)
+        for (int it = tid; it < MT * MCN_ENC; it += NT) {
+            const int m = it / MCN_ENC, ch = it - m * MCN_ENC;
+            if (row0 + m < total) a.d_enc_out[(size_t)(row0 + m) * MCN_ENC + ch] = X[mcn_swz(m, ch, XW)];
+        }
+    }
     // ---- encoding backward -> d xyz -> d rays_o / d rays_d
     //   enc channel 3+20c+f = w_f sin(2^f x_c), 3+20c+10+f = w_f cos(2^f x_c)  (w_f already inside enc_save)
     if (a.d_rays_o || a.d_rays_d) {
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             const int m = it / 3, c = it - m * 3;
             const long long g = row0 + m;
             float dx = 0.f;
-            if (g < total) {
+            if (g < total && !a.d_enc_out) {
                 const float* en = a.enc_save + (size_t)g * MCN_ENCP;
                 dx = X[mcn_swz(m, c, XW)];
 #pragma unroll

@@ -216,6 +216,27 @@ hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, float* 
     hipLaunchKernelGGL(encode_kernel, dim3((n * 30 + 255) / 256), dim3(256), 0, st, x, barf_w, n, out);
     return hipGetLastError();
 }
+// its backward: d x_c = d out_c + sum_f w_f 2^f (cos(2^f x_c) d sin_f - sin(2^f x_c) d cos_f); one thread per (point, axis)
+__global__ __launch_bounds__(256) void encode_bwd_kernel(const float* x, const float* barf_w, int n, const float* d_out, float* d_x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 3) return;
+    const int m = i / 3, c = i - m * 3;
+    const float xv = x[i];
+    const float* g = d_out + (size_t)m * MCN_ENC;
+    float dx = g[c];
+#pragma unroll
+    for (int f = 0; f < MCN_NFREQ; ++f) {
+        float s, co;
+        mcn_sincos(xv * (float)(1 << f), s, co);
+        dx = fmaf(barf_w[f] * (float)(1 << f), co * g[3 + c * 20 + f] - s * g[3 + c * 20 + 10 + f], dx);
+    }
+    d_x[i] = dx;
+}
+hipError_t mcn_launch_encode_bwd(const float* x, const float* barf_w, int n, const float* d_out, float* d_x, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(encode_bwd_kernel, dim3((n * 3 + 255) / 256), dim3(256), 0, st, x, barf_w, n, d_out, d_x);
+    return hipGetLastError();
+}
 
 // ---- The pixel subset of a train step: randperm(H * W)[:batch] (model/mc_nerf.py:329, a uniformly random ordered subset
 // without replacement) as `batch` evaluations of a keyed pseudo-random PERMUTATION of [0, n): a 6-round balanced Feistel

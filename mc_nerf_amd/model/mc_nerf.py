@@ -140,8 +140,12 @@ class NeRF_Model(nn.Module):
 
     # ------------------------------------------------------------------ per-pass API of the reference (:682-736)
     def inference(self, model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render=None, coarse=True, *, eps=None):
-        from .net_block import refuse_autograd
-        refuse_autograd("NeRF_Model.inference", [xyz, rays_d, z_vals, *model.parameters()])      # forward-only (docstring below)
+        """Reference :682-727.  Differentiable like the reference's: when autograd is recording and any input or parameter
+        requires a gradient the pass runs on the stand-alone differentiable kernels (`_inference_general`: EncodeFn, MlpApplyFn,
+        composites in tensor ops); otherwise on the fused forward-only path (`_inference`)."""
+        if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad
+                                           for t in (xyz, rays_d, z_vals, *model.parameters())):
+            return self._inference_general(model, embedding_xyz, step_r, xyz, rays_d, z_vals.float(), idx_render, eps)
         with torch.no_grad():
             return self._inference(model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render, coarse, eps=eps)
 
@@ -153,7 +157,7 @@ class NeRF_Model(nn.Module):
         `z_vals` has the reference's structure (its own call sites always do): `z_vals[n, j] = grid[j] + jitter[n]` with
         `grid` this model's coarse or fine grid, that path is taken and the origins are recovered from `xyz[:, 0]`.  Any
         other `xyz` / `z_vals` goes through the stand-alone kernels on the given positions (`_inference_general`).
-        Forward only: training differentiates through the fused `render_rays_train`.  `eps` is the N(0,1) draw of
+        Forward only (`inference` routes gradient requests to `_inference_general`).  `eps` is the N(0,1) draw of
         `sigma2weights` (drawn from the device generator when not given)."""
         N, S_ = z_vals.shape
         dev = rays_d.device
@@ -187,30 +191,26 @@ class NeRF_Model(nn.Module):
                                                       st.white_back, want_depth=True)
         return rgb, out[..., 0], xyz, depth, opacity
 
-    @torch.no_grad()
     def _inference_general(self, model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render, eps):
         """`inference` on arbitrary sample positions (reference :682-727 literally): encode the given `xyz` and run the net
-        with the stand-alone exact-fp32 kernels (`mcnerf_encode`, `mcnerf_mlp_apply`), scatter into the defaults
-        (sigma_default, white) when an index list is given, then both composites in tensor ops (:705-725)."""
+        with the stand-alone exact-fp32 kernels through the modules' own forwards (`SinCosEmbedding.forward`,
+        `CorseFine_NeRF.forward`: differentiable when a gradient is requested), scatter into the defaults (sigma_default,
+        white) when an index list is given, then both composites in tensor ops (:705-725)."""
         st = self.settings
         N, S_ = z_vals.shape
         dev = rays_d.device
-        rays_d = rays_d.float().contiguous()
+        rays_d = rays_d.float()
         xyz3 = xyz.reshape(N, S_, 3).float()
-        flat = model.flat_params()
-        packed = ops.pack_weights(model.net, flat, precision="f32")
-        barf_w = embedding_xyz.barf_weights_on(step_r, dev)
         if idx_render is None:
-            x = xyz3.reshape(-1, 3).contiguous()
-            dirs = rays_d.unsqueeze(1).expand(-1, S_, -1).reshape(-1, 3).contiguous()
-            out = ops.mlp_apply(model.net, flat, packed, ops.encode(x, barf_w), dirs).reshape(N, S_, 4)
+            dirs = rays_d.unsqueeze(1).expand(-1, S_, -1).reshape(-1, 3)
+            out = model(embedding_xyz(xyz3.reshape(-1, 3), step_r), dirs).reshape(N, S_, 4)
         else:
             r, j = idx_render[:, 0].long().to(dev), idx_render[:, 1].long().to(dev)
             out = torch.ones(N, S_, 4, dtype=torch.float32, device=dev)
             out[..., 0] = st.sigma_default
             if r.numel():
-                raw = ops.mlp_apply(model.net, flat, packed, ops.encode(xyz3[r, j].contiguous(), barf_w), rays_d[r].contiguous())
-                out[r, j] = raw
+                raw = model(embedding_xyz(xyz3[r, j], step_r), rays_d[r])
+                out = out.index_put((r, j), raw)
         if eps is None:
             eps = torch.randn(N, S_, device=dev)
         sig, rgbs = out[..., 0], out[..., 1:]

@@ -19,15 +19,48 @@ import torch.nn as nn
 from .. import _lib, ops
 
 
-def refuse_autograd(what, tensors):
-    """The stand-alone per-module forwards run HIP kernels that have no backward of their own (the differentiable path is
-    NeRF_Model.render_rays_train / MC_Model.forward, one fused autograd.Function).  A caller that would differentiate
-    through them (model/net_block.py:20-35, 67-78 are differentiable in the reference) gets an error, not a tensor
-    without a graph."""
-    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
-        raise _lib.McnerfError(f"{what} is forward-only on the HIP path and was called with autograd recording on tensors that "
-                               "require a gradient: wrap the call in torch.no_grad(), or train through NeRF_Model.render_rays_train / "
-                               "MC_Model.forward (the fused differentiable render)")
+class EncodeFn(torch.autograd.Function):
+    """SinCosEmbedding.forward (model/net_block.py:20-35) as a differentiable stand-alone call: mcnerf_encode / mcnerf_encode_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, barf_w):
+        flat = x.reshape(-1, 3).float().contiguous()
+        ctx.save_for_backward(flat, barf_w)
+        ctx.shape = x.shape
+        return ops.encode(flat, barf_w).reshape(*x.shape[:-1], 63)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        flat, barf_w = ctx.saved_tensors
+        d_x = ops.encode_bwd(flat, barf_w, d_out.reshape(-1, 63).float().contiguous())
+        return d_x.reshape(ctx.shape), None
+
+
+class MlpApplyFn(torch.autograd.Function):
+    """CorseFine_NeRF.forward (model/net_block.py:67-78) as a differentiable stand-alone call on caller-supplied encodings:
+    the exact-fp32 fused forward with saved operands, its backward chain (d x, d dirs) and the weight-gradient kernel.  The
+    parameters enter as ONE flat buffer (`module.flat_params()`); its gradient comes back flat and autograd slices it into the
+    per-parameter views."""
+
+    @staticmethod
+    def forward(ctx, module, x, dirs, flat):
+        net = module.net
+        packed = ops.pack_weights(net, flat, precision="f32")
+        xe, dd = x.reshape(-1, 63).float().contiguous(), dirs.reshape(-1, 3).float().contiguous()
+        out, save = ops.mlp_apply_save(net, flat, packed, xe, dd)
+        ctx.net, ctx.save, ctx.packed = net, save, packed
+        ctx.save_for_backward(flat, dd, out)
+        ctx.shapes = (x.shape, dirs.shape)
+        return out.reshape(*x.shape[:-1], 4)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        flat, dd, out = ctx.saved_tensors
+        grads = torch.zeros_like(flat) if ctx.needs_input_grad[3] else None
+        d_x, d_dirs = ops.mlp_apply_bwd(ctx.net, flat, ctx.packed, dd, out, d_out.reshape(-1, 4).float().contiguous(), ctx.save, grads)
+        ctx.save = None
+        return (None, d_x.reshape(ctx.shapes[0]) if ctx.needs_input_grad[1] else None,
+                d_dirs.reshape(ctx.shapes[1]) if ctx.needs_input_grad[2] else None, grads)
 
 
 class SinCosEmbedding(nn.Module):
@@ -68,17 +101,14 @@ class SinCosEmbedding(nn.Module):
         return ops.upload_f32(w, device) if torch.device(device).type == "cuda" else w.to(device)
 
     def forward(self, x, step_r):
-        """Reference :20-35: [..., 3] -> [..., 63].  Stand-alone, FORWARD-ONLY call of the HIP encoding kernel (the render
-        path computes the encoding inside the fused MLP kernels and differentiates it there): asked for a gradient it
-        raises instead of returning a silently detached tensor."""
-        refuse_autograd("SinCosEmbedding.forward", [x])
-        with torch.no_grad():
-            return self._forward(x, step_r)
-
-    def _forward(self, x, step_r):
-        flat = x.reshape(-1, 3).float().contiguous()
-        out = ops.encode(flat, self.barf_weights_on(step_r, flat.device))
-        return out.reshape(*x.shape[:-1], self.out_channels)
+        """Reference :20-35: [..., 3] -> [..., 63].  Stand-alone call of the HIP encoding kernel (the render path computes the
+        encoding inside the fused MLP kernels and differentiates it there); differentiable with respect to x like the
+        reference's (EncodeFn)."""
+        bw = self.barf_weights_on(step_r, x.device)
+        if torch.is_grad_enabled() and x.requires_grad:
+            return EncodeFn.apply(x, bw)
+        flat = x.detach().reshape(-1, 3).float().contiguous()
+        return ops.encode(flat, bw).reshape(*x.shape[:-1], self.out_channels)
 
 
 class CorseFine_NeRF(nn.Module):
@@ -147,17 +177,37 @@ class CorseFine_NeRF(nn.Module):
         return [flat_grad[off:off + p.numel()].view(p.shape)
                 for p, off in zip(self.ordered_parameters(), self._offsets)]
 
+    def flat_params_autograd(self) -> torch.Tensor:
+        """The flat parameter buffer as a node of the autograd graph: differentiating through it delivers the flat gradient to
+        every parameter's .grad (per-parameter views), so a stand-alone differentiable forward trains like the reference's."""
+        flat = self.flat_params()
+        params = self.ordered_parameters()
+        return _FlatOf.apply(self, flat, *params)
+
     def forward(self, x, dirs):
         """Reference :67-78: encoded positions x [M,63] and view directions dirs [M,3] -> [M,4] = (sigma_raw, rgb).
-        Stand-alone, FORWARD-ONLY call of the exact-fp32 fused kernel on caller-supplied encodings (training
-        differentiates through the fused NeRF_Model.render_rays_train): with autograd recording and a parameter or input
-        that requires a gradient it raises (wrap the call in torch.no_grad() for inference) instead of silently returning a
-        detached tensor that would train nothing."""
-        refuse_autograd("CorseFine_NeRF.forward", [x, dirs, *self.parameters()])
-        with torch.no_grad():
-            return self._forward(x, dirs)
-
-    def _forward(self, x, dirs):
+        Stand-alone call of the exact-fp32 fused kernel on caller-supplied encodings (training normally differentiates
+        through the fused NeRF_Model.render_rays_train).  Differentiable like the reference's with respect to x, dirs and
+        every parameter (MlpApplyFn); without a gradient request it is the forward-only kernel."""
+        needs = torch.is_grad_enabled() and (x.requires_grad or dirs.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs:
+            return MlpApplyFn.apply(self, x, dirs, self.flat_params_autograd())
         flat = self.flat_params()
         packed = ops.pack_weights(self.net, flat, precision="f32")
-        return ops.mlp_apply(self.net, flat, packed, x.float().contiguous(), dirs.float().contiguous())
+        return ops.mlp_apply(self.net, flat, packed, x.detach().reshape(-1, 63).float().contiguous(),
+                             dirs.detach().reshape(-1, 3).float().contiguous()).reshape(*x.shape[:-1], 4)
+
+
+class _FlatOf(torch.autograd.Function):
+    """Identity on the flat buffer whose backward hands each parameter its slice of the flat gradient."""
+
+    @staticmethod
+    def forward(ctx, module, flat, *params):
+        ctx.module = module
+        return flat.detach().view_as(flat)
+
+    @staticmethod
+    def backward(ctx, g):
+        views = ctx.module.grad_views(g)
+        params = ctx.module.ordered_parameters()
+        return (None, None, *[v.clone() if p.requires_grad else None for v, p in zip(views, params)])

@@ -236,6 +236,41 @@ def mlp_apply(net: Net, params: Tensor, packed: Tensor, x_enc: Tensor, dirs: Ten
     return out
 
 
+def encode_bwd(x: Tensor, barf_w: Tensor, d_out: Tensor) -> Tensor:
+    """Backward of `encode`: d_out [n,63] -> d_x [n,3]."""
+    n = x.shape[0]
+    d_x = torch.empty(n, 3, dtype=torch.float32, device=x.device)
+    _lib.call("mcnerf_encode_bwd", _p(x), _p(barf_w), n, _p(d_out), _p(d_x), _stream())
+    return d_x
+
+
+def mlp_apply_save(net: Net, params: Tensor, packed: Tensor, x_enc: Tensor, dirs: Tensor) -> Tuple[Tensor, MlpSave]:
+    """`mlp_apply` that keeps the operands of its backward (exact-fp32 workspaces)."""
+    n = x_enc.shape[0]
+    out = torch.empty(n, 4, dtype=torch.float32, device=x_enc.device)
+    save = alloc_save(net, n, x_enc.device, "f32")
+    _lib.call("mcnerf_mlp_apply_save", *net.triple, _p(params), _p(packed), _p(x_enc), _p(dirs), n, _p(out),
+              _p(save.act), save.capacity, _p(save.enc), _p(save.sh), _p(save.mask, torch.int32), _stream())
+    return out, save
+
+
+def mlp_apply_bwd(net: Net, params: Tensor, packed: Tensor, dirs: Tensor, out: Tensor, d_out: Tensor, save: MlpSave,
+                  grads: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    """Backward of `mlp_apply_save`: -> (d_x_enc [n,63], d_dirs [n,3]); the parameter gradients are ACCUMULATED into the flat
+    `grads` (layout of the parameter buffer) unless it is None."""
+    n = dirs.shape[0]
+    dev = dirs.device
+    dy, dsh = torch.empty_like(save.act), torch.empty_like(save.sh)
+    d_x = torch.empty(n, 63, dtype=torch.float32, device=dev)
+    z = torch.zeros(n * 3 + 1, dtype=torch.float32, device=dev)          # (d_dirs accumulator + the zero sample depth, one fill)
+    d_dirs = z[:n * 3].view(n, 3)
+    _lib.call("mcnerf_mlp_apply_bwd", *net.triple, _p(params), _p(packed), _p(dirs), _p(z[n * 3:]), n, _p(out), _p(d_out),
+              _p(save.mask, torch.int32), save.capacity, _p(save.enc), _p(save.sh), _p(dy), _p(dsh), _p(d_x), _p(d_dirs), _stream())
+    if grads is not None:
+        mlp_dw(net, save, dy, dsh, grads, n)
+    return d_x, d_dirs
+
+
 def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, zgrid: Tensor,
             jitter: Optional[Tensor], barf_w: Tensor, out: Tensor, d_out: Tensor, save: MlpSave,
             dy: Tensor, dsh: Tensor, d_rays_o: Optional[Tensor], d_rays_d: Optional[Tensor],

@@ -192,21 +192,22 @@ def select_fine(weights: Tensor, cfg: RenderCfg) -> Tensor:
 
 # --------------------------------------------------------------------------- inference
 def inference(p: Dict[str, Tensor], net: NetCfg, cfg: RenderCfg, step_r: float,
-              rays_o: Tensor, rays_d: Tensor, z_vals: Tensor, eps: Tensor,
-              idx_render: Optional[Tensor] = None):
-    """NeRF_Model.inference (model/mc_nerf.py:682-727) for one net.
+              rays_o: Optional[Tensor], rays_d: Tensor, z_vals: Tensor, eps: Tensor,
+              idx_render: Optional[Tensor] = None, xyz: Optional[Tensor] = None):
+    """NeRF_Model.inference (model/mc_nerf.py:682-727) for one net.  The reference takes the sample positions `xyz`
+    [N,S,3] as an argument (its callers compute o + d z, :602 / :637); here they are built from `rays_o` unless given.
 
     Returns rgb [N,3], sigmas [N,S], depth [N,1], opacity [N,1], sig_rgb [N,S,4].
     """
     N, S = z_vals.shape
+    if xyz is None:
+        xyz = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z_vals.unsqueeze(2)
     if idx_render is None:
-        xyz = (rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z_vals.unsqueeze(2)).reshape(-1, 3)
         dirs = rays_d.unsqueeze(1).expand(-1, S, -1).reshape(-1, 3)
-        out = mlp_forward(p, net, embed(xyz, step_r, cfg), dirs).reshape(N, S, 4)
+        out = mlp_forward(p, net, embed(xyz.reshape(-1, 3), step_r, cfg), dirs).reshape(N, S, 4)
     else:
         r, j = idx_render[:, 0], idx_render[:, 1]
-        xyz = rays_o[r] + rays_d[r] * z_vals[r, j].unsqueeze(-1)
-        out_k = mlp_forward(p, net, embed(xyz, step_r, cfg), rays_d[r])
+        out_k = mlp_forward(p, net, embed(xyz[r, j], step_r, cfg), rays_d[r])
         sig0 = torch.full((N, S, 1), cfg.sigma_default)
         out = torch.cat([sig0, torch.ones(N, S, 3)], dim=-1)
         out = out.index_put((r, j), out_k)

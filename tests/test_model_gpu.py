@@ -791,9 +791,23 @@ def test_inference_and_sigma2weights_api(gpu_device, precision):
         assert err(got[0], rgb.numpy()) < TOL and err(got[3], depth.numpy()) < TOL and err(got[4], opac.numpy()) < TOL
         assert err(got[1], sig.numpy()) < 1e-4 * max(1.0, float(sig.abs().max()))
         assert got[2].shape == xyz.shape
-    from mc_nerf_amd._lib import McnerfError
-    with pytest.raises(McnerfError, match="forward-only"):        # (reference :682-727 is differentiable; this one says so instead of detaching)
-        m.inference(m.nerf_coarse, m.emmbedding_xyz, 1.0, xyz.to(dev), d.to(dev), z.to(dev), None, True)
+    # the per-pass API is differentiable like the reference's (:682-727): with autograd recording, the fine pass on the index list
+    # gives the oracle's gradients with respect to the sample positions, the directions and every parameter of the net
+    pf_g = {k: v.clone().requires_grad_(True) for k, v in pf.items()}
+    xyz_r, d_r = xyz.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    rgb_r, sig_r, depth_r, _, _ = O.inference(pf_g, cfg.fine, cfg, 1.0, None, d_r, z, kw["eps_f"], idx, xyz=xyz_r)
+    wts = torch.rand(n, 3, generator=torch.Generator().manual_seed(3))
+    ((rgb_r * wts).sum() + depth_r.sum() * 0.1 + (sig_r * 1e-3).sum()).backward()
+    xyz_g, d_g = xyz.to(dev).requires_grad_(True), d.to(dev).requires_grad_(True)
+    for p_ in m.nerf_fine.parameters():
+        p_.grad = None
+    got = m.inference(m.nerf_fine, m.emmbedding_xyz, 1.0, xyz_g, d_g, z.to(dev), idx.to(dev), False, eps=kw["eps_f"].to(dev))
+    assert got[0].requires_grad and err(got[0], rgb_r.detach().numpy()) < TOL
+    ((got[0] * wts.to(dev)).sum() + got[3].sum() * 0.1 + (got[1] * 1e-3).sum()).backward()
+    rel = lambda a, b: float((a.detach().cpu() - b).abs().max()) / max(1e-6, float(b.abs().max()))
+    assert rel(xyz_g.grad, xyz_r.grad) < 1e-4 and rel(d_g.grad, d_r.grad) < 1e-4
+    for k, p_ in m.nerf_fine.named_parameters():
+        assert p_.grad is not None and rel(p_.grad, pf_g[k].grad) < 1e-4, k
     dl, sg, ep = torch.rand(7, 16) + 0.05, torch.randn(7, 16) * 3, torch.randn(7, 16)
     assert err(m.sigma2weights(dl.to(dev), sg.to(dev), ep.to(dev)), O.sigma2weights(dl, sg, ep).numpy()) < 2e-6
     # arbitrary sample positions (not grid + jitter, a sample count of its own): the general path on the stand-alone kernels
@@ -959,11 +973,34 @@ def test_standalone_module_forwards_match_reference_modules(gpu_device):
             out = net(x_enc.to(dev), dirs.to(dev))
         ref = O.mlp_forward(p, nc, x_enc, dirs)
         assert out.shape == (777, 4) and float((out.cpu() - ref).abs().max()) < 2e-5
-        # the stand-alone forwards have no backward (the differentiable path is the fused render): a caller that would train
-        # through them gets an error, never a silently detached tensor
-        from mc_nerf_amd._lib import McnerfError
-        with pytest.raises(McnerfError, match="forward-only"):
-            net(x_enc.to(dev), dirs.to(dev))                        # parameters require grad, autograd is recording
-    with pytest.raises(McnerfError, match="forward-only"):
-        emb(x.to(dev).requires_grad_(True), 0.5)
+        # ... and differentiable like the reference's modules: gradients with respect to the encodings, the directions and
+        # every parameter against torch autograd over the oracle
+        pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        xe_r, dr_r = x_enc.clone().requires_grad_(True), dirs.clone().requires_grad_(True)
+        wts = torch.rand(777, 4, generator=torch.Generator().manual_seed(seed))
+        (O.mlp_forward(pg, nc, xe_r, dr_r) * wts).sum().backward()
+        xe_g, dr_g = x_enc.to(dev).requires_grad_(True), dirs.to(dev).requires_grad_(True)
+        out_g = net(xe_g, dr_g)
+        assert out_g.requires_grad and torch.equal(out_g.detach(), out)
+        (out_g * wts.to(dev)).sum().backward()
+        rel = lambda a, b: float((a.detach().cpu() - b).abs().max()) / max(1e-6, float(b.abs().max()))
+        assert rel(xe_g.grad, xe_r.grad) < 1e-4 and rel(dr_g.grad, dr_r.grad) < 1e-4
+        for k, p_ in net.named_parameters():
+            assert p_.grad is not None and rel(p_.grad, pg[k].grad) < 1e-4, k
+        # frozen parameters: inputs only
+        for p_ in net.parameters():
+            p_.requires_grad_(False); p_.grad = None
+        xe_g2 = x_enc.to(dev).requires_grad_(True)
+        (net(xe_g2, dirs.to(dev)) * wts.to(dev)).sum().backward()
+        assert rel(xe_g2.grad, xe_r.grad) < 1e-4 and all(p_.grad is None for p_ in net.parameters())
+    emb.barf_mode = True
+    for step_r in (0.1, 0.55):
+        xr = x.clone().requires_grad_(True)
+        we = torch.rand(777, 63, generator=torch.Generator().manual_seed(2))
+        (O.embed(xr, step_r, cfg) * we).sum().backward()
+        xg = x.to(dev).requires_grad_(True)
+        eg = emb(xg, step_r)
+        assert eg.requires_grad
+        (eg * we.to(dev)).sum().backward()
+        assert float((xg.grad.cpu() - xr.grad).abs().max()) < 1e-4 * max(1.0, float(xr.grad.abs().max()))
     assert not emb(x.to(dev), 0.5).requires_grad                   # nothing requires a gradient: plain inference call
