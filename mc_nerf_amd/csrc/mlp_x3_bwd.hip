@@ -43,6 +43,15 @@ __device__ __forceinline__ void mcnx3_bwd_seg(Mcn16Ring& ring, char* smem, int l
     constexpr int LASTA = EPI ? START + 14 / IPG : 0;             // gap of the last item that reads the accumulator (item 14)
     constexpr int INIT_G = (G - 8) > LASTA ? (G - 8) : LASTA;     // the next tile's accumulator (= the set just drained) is initialised from here,
     constexpr int INIT_N = (INIT_G + 3 <= G - 1) ? 4 : 1;         // a quarter per gap where there is room
+    // (the four fragment stores of a tile, one every SSTR gaps behind the word items where the tile has room: mlp_x3_fwd.hip)
+#ifndef MCNX3_NO_SPREAD
+    constexpr int SBASE = START + 16, SSTR = (G - SBASE) / 4;
+    constexpr bool STAG = (MODE == 1 || MODE == 2) && IPG == 1 && SSTR >= 2;
+#else
+    constexpr int SBASE = 0, SSTR = 1;
+    constexpr bool STAG = false;
+#endif
+    constexpr int NITG = STAG ? 16 : NIT;
     Mcn16Cursor cur;
     u32x4_t afh[MCNX3_PF], afl[MCNX3_PF];
     f32x16 acc[2];
@@ -110,7 +119,9 @@ __device__ __forceinline__ void mcnx3_bwd_seg(Mcn16Ring& ring, char* smem, int l
                 if (EPI && t > 0 && gap >= START) {
 #pragma unroll
                     for (int i = (gap - START) * IPG; i < (gap - START + 1) * IPG; ++i)
-                        if (i < NIT) item(acc[(t - 1) & 1], t - 1, i);
+                        if (i < NITG) item(acc[(t - 1) & 1], t - 1, i);
+                    if (STAG && gap >= SBASE && (gap - SBASE) / SSTR < 4 && (gap - SBASE) % SSTR == 0)
+                        item(acc[(t - 1) & 1], t - 1, 16 + (gap - SBASE) / SSTR);
                 }
                 if (EPI && t + 1 < NTILES && gap >= INIT_G && gap < INIT_G + INIT_N) {
 #pragma unroll

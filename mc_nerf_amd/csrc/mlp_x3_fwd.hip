@@ -40,6 +40,17 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
     constexpr int IPG = (NIT + (G - START) - 1) / (G - START);    // items per gap
     constexpr int LASTG = START + (NIT + IPG - 1) / IPG - 1;      // gap of the last item
     constexpr int BIAS_G = (G - 6) > LASTG ? (G - 6) : LASTG;     // the next tile's accumulator (= the set just drained) is loaded here
+    // The four fragment stores of a tile are not issued back to back behind the word items but one every SSTR gaps over the rest
+    // of the tile where it has the gaps for it (same-box A/B, 3.28 M rows: saving forward 12.12 -> 11.72 ms, backward 11.46 ->
+    // 11.33 ms).  (Giving every (store, wave) pair a gap of its own costs a scalar branch per store: + 15 %.)
+#ifndef MCNX3_NO_SPREAD
+    constexpr int SBASE = START + 8 * IPW, SSTR = (G - SBASE) / 4;
+    constexpr bool STAG = SAVE && IPG == 1 && SSTR >= 2;
+#else
+    constexpr int SBASE = 0, SSTR = 1;
+    constexpr bool STAG = false;
+#endif
+    constexpr int NITG = STAG ? 8 * IPW : NIT;                    // items placed by the item-per-gap rule
     Mcn16Cursor cur;
     unsigned mw[MW];
 #pragma unroll
@@ -121,7 +132,9 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
                 if (t > 0 && gap >= START) {
 #pragma unroll
                     for (int i = (gap - START) * IPG; i < (gap - START + 1) * IPG; ++i)
-                        if (i < NIT) item(acc[(t - 1) & 1], t - 1, i);
+                        if (i < NITG) item(acc[(t - 1) & 1], t - 1, i);
+                    if (STAG && gap >= SBASE && (gap - SBASE) / SSTR < 4 && (gap - SBASE) % SSTR == 0)
+                        item(acc[(t - 1) & 1], t - 1, 8 * IPW + (gap - SBASE) / SSTR);
                 }
 #endif
                 if (gap == BIAS_G && t + 1 < NT) bias_init(acc[(t + 1) & 1], t + 1);
