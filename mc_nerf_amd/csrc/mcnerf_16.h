@@ -239,7 +239,11 @@ struct Mcn16Ring {
     unsigned issue_slot;      // ring slot (0..RING-1) of the next issue
     unsigned sync_slot;       // ring slot of the next slab to synchronise
     unsigned next_off;        // LDS byte offset of the slab synchronised last (the one after the slab being consumed)
-    const char* piece_src;    // (mcnerf_x3.h, spread refill) this lane's source address of piece 0 of the slab being refilled
+    // (mcnerf_x3.h: the source address is split into a wave-uniform base -- scalar registers -- and the lane's 32-bit byte offset,
+    //  the SADDR form of global_load_lds: no 64-bit per-lane pointer stays live across the layers)
+    const char* ubase;        // packed stream + this wave's first piece inside a slab (wave-uniform)
+    unsigned voff;            // lane * 16
+    const char* piece_base;   // (spread refill) wave-uniform source address of piece 0 of the slab being refilled
 #ifdef ABL16_NORING
     bool first_fill;
 #endif

@@ -88,12 +88,18 @@ __device__ __forceinline__ void mcnx3_mfma3(f32x16& acc, const u32x4_t& ah, cons
 }
 
 // ---- the shared weight ring with PPW pieces per wave and slab (Mcn16Ring state, mcnerf_16.h)
+// One 1 KiB piece, source = wave-uniform base (scalar register pair) + the lane's byte offset (SADDR form), LDS destination through M0.
+__device__ __forceinline__ void mcnx3_dma16(const char* ubase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(ubase), "s"(lds_dst) : "memory");
+}
 template <int PPW>
 __device__ __forceinline__ void mcnx3_ring_issue(Mcn16Ring& r) {
-    const char* s = r.src + (size_t)r.src_slab * (MCN16_SLAB * 1024);
+    const char* s = r.ubase + (size_t)r.src_slab * (MCN16_SLAB * 1024);
     const unsigned d = r.lds_base + r.issue_slot * (MCN16_SLAB * 1024) + r.lds_piece;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) mcn16_dma16(s + i * 1024, d + i * 1024);
+    for (int i = 0; i < PPW; ++i) mcnx3_dma16(s + i * 1024, r.voff, d + i * 1024);
     r.src_slab = (r.src_slab + 1 == r.n_slabs) ? 0 : r.src_slab + 1;
     r.issue_slot = (r.issue_slot + 1) & (MCN16_RING - 1);
 }
@@ -110,7 +116,9 @@ __device__ __forceinline__ void mcnx3_ring_sync(Mcn16Ring& r) {
 }
 template <int PPW>
 __device__ __forceinline__ void mcnx3_ring_start(Mcn16Ring& r, char* ring_lds, const void* packed, int n_slabs, int wave, int lane) {
-    r.src = reinterpret_cast<const char*>(packed) + (PPW * wave) * 1024 + lane * 16;
+    r.ubase = reinterpret_cast<const char*>(packed) + (PPW * wave) * 1024;
+    r.voff = lane * 16;
+    r.src = nullptr;
     r.lds_piece = (PPW * wave) * 1024;
     r.lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)ring_lds);
     r.src_slab = 0; r.n_slabs = n_slabs; r.issue_slot = 0; r.sync_slot = 0; r.next_off = 0;
@@ -139,20 +147,21 @@ __device__ __forceinline__ void mcnx3_before_mfma(Mcn16Ring& r, Mcn16Cursor& c, 
 #ifndef MCNX3_DMA_STEP
 #define MCNX3_DMA_STEP 2
 #endif
-// The refill's addresses are set up ONCE per slab at the synchronisation point -- the lane's source address in a register pair,
-// the LDS destination in M0 (nothing else in these kernels uses M0; the other LDS-DMA helpers save and restore it) -- and
-// every piece is then a single instruction: the instruction's immediate offset advances both the global and the LDS address,
-// and a slab's pieces are 1 KiB apart in both.
+// The refill's addresses are set up ONCE per slab at the synchronisation point -- the wave-uniform source address in a scalar
+// register pair, the LDS destination in M0 (nothing else in these kernels uses M0; the other LDS-DMA helpers save and restore it) --
+// and every piece is then a single instruction: the instruction's immediate offset advances both the global and the LDS address,
+// and a slab's pieces are 1 KiB apart in both.  (A per-lane 64-bit source pointer kept across the layers was the one value the
+// 512-register saving forward spilled: reloaded from scratch at every slab of the sigma head, each reload a full vmcnt(0) drain.)
 template <int PPW>
 __device__ __forceinline__ void mcnx3_ring_piece(Mcn16Ring& r, int i) {
 #ifdef ABLX3_NODMA            // (timing-only: the ring is never refilled)
     return;
 #endif
     switch (i) {              // (immediate offsets)
-        case 0: asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(r.piece_src) : "memory"); break;
-        case 1: asm volatile("global_load_lds_dwordx4 %0, off offset:1024" ::"v"(r.piece_src) : "memory"); break;
-        case 2: asm volatile("global_load_lds_dwordx4 %0, off offset:2048" ::"v"(r.piece_src) : "memory"); break;
-        default: asm volatile("global_load_lds_dwordx4 %0, off offset:3072" ::"v"(r.piece_src) : "memory"); break;
+        case 0: asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(r.voff), "s"(r.piece_base) : "memory"); break;
+        case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(r.voff), "s"(r.piece_base) : "memory"); break;
+        case 2: asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(r.voff), "s"(r.piece_base) : "memory"); break;
+        default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(r.voff), "s"(r.piece_base) : "memory"); break;
     }
 }
 template <int F, int PPW>
@@ -165,7 +174,7 @@ __device__ __forceinline__ void mcnx3_before_mfma_spread(Mcn16Ring& r, Mcn16Curs
 #endif
         r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
         r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
-        r.piece_src = r.src + (size_t)r.src_slab * (MCN16_SLAB * 1024);
+        r.piece_base = r.ubase + (size_t)r.src_slab * (MCN16_SLAB * 1024);
         asm volatile("s_mov_b32 m0, %0" ::"s"(r.lds_base + r.issue_slot * (MCN16_SLAB * 1024) + r.lds_piece) : "memory");
         r.src_slab = (r.src_slab + 1 == r.n_slabs) ? 0 : r.src_slab + 1;
         r.issue_slot = (r.issue_slot + 1) & (MCN16_RING - 1);

@@ -36,21 +36,26 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
     constexpr bool HAS2 = SAVE || EPI == 1;                       // a word has a second item (ReLU bit, sigma dot)
     constexpr int IPW = HAS2 ? 3 : 2;                             // items per packed word
     constexpr int NIT = 8 * IPW + (SAVE ? 4 : 0);                 // work items of one tile's epilogue (each <= 6 vector instructions)
-    constexpr int START = G >= NIT + 4 ? 3 : 0;                   // first gap that carries an item (the previous tile's last MFMA must land)
-    constexpr int IPG = (NIT + (G - START) - 1) / (G - START);    // items per gap
-    constexpr int LASTG = START + (NIT + IPG - 1) / IPG - 1;      // gap of the last item
-    constexpr int BIAS_G = (G - 6) > LASTG ? (G - 6) : LASTG;     // the next tile's accumulator (= the set just drained) is loaded here
-    // The four fragment stores of a tile are not issued back to back behind the word items but one every SSTR gaps over the rest
-    // of the tile where it has the gaps for it (same-box A/B, 3.28 M rows: saving forward 12.12 -> 11.72 ms, backward 11.46 ->
-    // 11.33 ms).  (Giving every (store, wave) pair a gap of its own costs a scalar branch per store: + 15 %.)
+    // Placement of a tile's epilogue in the gaps of the next tile.  With fragment stores (SAVE) and room for it: the word items from
+    // gap 3 (the previous tile's last MFMA must have landed), IPG per gap, then the four stores one every SSTR gaps over the rest of
+    // the tile instead of back to back (same-box A/B, 3.28 M rows of the 256-wide net: saving forward 12.12 -> 11.72 ms, backward
+    // 11.46 -> 11.33 ms; a gap of its own per (store, wave) pair needs a scalar branch per store and costs + 15 %).  Otherwise all
+    // items in order, as many per gap as it takes.
+    constexpr int NWI = 8 * IPW;                                  // word items
 #ifndef MCNX3_NO_SPREAD
-    constexpr int SBASE = START + 8 * IPW, SSTR = (G - SBASE) / 4;
-    constexpr bool STAG = SAVE && IPG == 1 && SSTR >= 2;
+    constexpr int ROOM = G - 3 - 8;                               // gaps for the word items when every store gets two
+    constexpr int IPGA = ROOM > 0 ? (NWI + ROOM - 1) / ROOM : 99;
+    constexpr bool STAG = SAVE && IPGA <= 2;
 #else
-    constexpr int SBASE = 0, SSTR = 1;
+    constexpr int IPGA = 99;
     constexpr bool STAG = false;
 #endif
-    constexpr int NITG = STAG ? 8 * IPW : NIT;                    // items placed by the item-per-gap rule
+    constexpr int START = STAG ? 3 : (G >= NIT + 4 ? 3 : 0);      // first gap that carries an item
+    constexpr int IPG = STAG ? IPGA : (NIT + (G - START) - 1) / (G - START);    // items per gap
+    constexpr int NITG = STAG ? NWI : NIT;                        // items placed by the items-per-gap rule
+    constexpr int LASTG = START + (NITG + IPG - 1) / IPG - 1;     // gap of the last of them
+    constexpr int SBASE = LASTG + 1, SSTR = STAG ? (G - SBASE) / 4 : 1;
+    constexpr int BIAS_G = (G - 6) > LASTG ? (G - 6) : LASTG;     // the next tile's accumulator (= the set just drained) is loaded here
     Mcn16Cursor cur;
     unsigned mw[MW];
 #pragma unroll
