@@ -412,21 +412,23 @@ def run_rank(args):
         pc = head["per_call"]
         # The dominant KERNEL is the longest single launch.  In the register-chain modes (f16x3, f16, bf16) every fine-net call
         # is one launch and the weight-gradient kernel is the longest; in f32 mlp_dw is 15 launches per call (aggregate in
-        # `per_call`) and the longest launch is a chain.  SURVEY 8(d) names the bound of this path as MFMA: `frac` is the MFMA fraction of
-        # that kernel; the HBM roof (contract bytes and measured PMC bytes) sits beside it in `other_roof` -- for the
-        # weight-gradient kernel THAT is the roof that binds (it streams its GEMM operands once: `binding_roof`).
+        # `per_call`) and the longest launch is a chain.  `roofline` prices that kernel against the roof that BINDS it (the
+        # larger of its two fractions): the weight-gradient kernel streams its GEMM operands once and is HBM-bound -- achieved =
+        # contract (algorithmic) bytes per launch / its duration, `traffic` = the PMC-measured bytes -- the chains are MFMA-bound
+        # (algorithmic FLOPs against the dense f16 peak).  The other roof of the same kernel sits in `other_roof`.
         single = pc if args.precision != "f32" else {k: v for k, v in pc.items() if k != "mlp_dw<256>"}
         dom = max(single, key=lambda k: single[k]["ms"])
         mfma_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
         traffic, tsrc = pmc_traffic(args.precision, dom) if args.rays == 32768 else (None, None)
-        roof = {"bound": "mfma", "kernel": dom, "achieved": pc[dom]["mfma_TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
-                "frac": pc[dom]["mfma_frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": tsrc,
-                "other_roof": {"bound": "hbm", "contract_bytes_per_launch": pc[dom]["contract_bytes_per_launch"],
-                               "contract_GBs": pc[dom]["hbm_GBs"], "contract_frac": pc[dom]["hbm_GBs"] / PEAK_HBM_GBS,
-                               "pmc_bytes_per_launch": traffic,
-                               "pmc_over_contract": (traffic / pc[dom]["contract_bytes_per_launch"]) if traffic else None,
-                               "peak_GBs": PEAK_HBM_GBS},
-                "binding_roof": "hbm" if pc[dom]["hbm_frac"] > pc[dom]["mfma_frac"] else "mfma",
+        hbm_roof = {"bound": "hbm", "achieved": pc[dom]["hbm_GBs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": pc[dom]["hbm_frac"],
+                    "contract_bytes_per_launch": pc[dom]["contract_bytes_per_launch"],
+                    "pmc_over_contract": (traffic / pc[dom]["contract_bytes_per_launch"]) if traffic else None}
+        mfma_roof = {"bound": "mfma", "achieved": pc[dom]["mfma_TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s", "frac": pc[dom]["mfma_frac"]}
+        first, second = (hbm_roof, mfma_roof) if pc[dom]["hbm_frac"] > pc[dom]["mfma_frac"] else (mfma_roof, hbm_roof)
+        roof = {"bound": first["bound"], "kernel": dom, "ms": pc[dom]["ms"], "achieved": first["achieved"], "peak": first["peak"],
+                "unit": first["unit"], "frac": first["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                "traffic_source": tsrc, "contract_bytes_per_launch": hbm_roof["contract_bytes_per_launch"],
+                "pmc_over_contract": hbm_roof["pmc_over_contract"], "other_roof": second,
                 "per_call": pc, "step_algorithmic_tflop": head["step_algorithmic_tflop"], "step_mfma_frac": head["step_mfma_frac"]}
         out = {
             "metric": "train rays/sec (coarse+fine, 64+128 samples)", "value": head["value"], "unit": "rays/s",
