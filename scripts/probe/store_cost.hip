@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void tile_loop(const f16x8* __restrict__ in, c
 }
 
 int main() {
-    const int cus = 256, iters = 3000;
+    const int cus = 256, iters = 9000;
     std::vector<_Float16> h((size_t)2 * 131072 * 8);
     srand(1);
     for (auto& x : h) x = (_Float16)((rand() / (float)RAND_MAX - 0.5f) * 0.25f);
@@ -63,6 +63,7 @@ int main() {
     hipMemcpy(din, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     const char* names[6] = {"no stores", "4 stores back to back", "1 store every 12 MFMAs", "spread, wave 0 of the workgroup only", "spread, as 8 dwordx2", "spread, default cache policy"};
     void (*kerns[6])(const f16x8*, char*, size_t, float*, int, unsigned long long*) = {tile_loop<0>, tile_loop<1>, tile_loop<2>, tile_loop<3>, tile_loop<4>, tile_loop<5>};
+    for (int rep = 0; rep < 2; ++rep)
     for (int mode = 0; mode < 6; ++mode) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(kerns[mode], dim3(cus), dim3(256), 0, 0, din, ws, ws_bytes - 1, dout, iters / 8, dclk);

@@ -26,5 +26,6 @@ $B --rig room --img 1600 --samples 64 --scale 4 2>/dev/null | tail -1 > gpurun_o
 python3 bench.py --mode render --steps 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_render_f16x3.json
 python3 bench.py --mode render --steps 3 --precision f16 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_render_f16.json
 scripts/probe/mfma_peak > gpurun_out/${TAG}_mfma_peak.txt 2>&1
+scripts/probe/store_cost > gpurun_out/${TAG}_store_cost.txt 2>&1
 python3 scripts/sparsity_probe.py 2>/dev/null > gpurun_out/${TAG}_sparsity.txt
 ls gpurun_out | grep ${TAG}_
