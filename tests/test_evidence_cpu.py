@@ -1,0 +1,55 @@
+"""The committed measurement evidence follows bench.py's contract and belongs to the kernel sources in the tree: the bench line
+under profiles/ carries the fields the driver reads (metric, value, roofline, cpu_baseline ...), its roofline arithmetic is
+consistent, and the PMC traffic files bench.py attaches to `roofline.traffic` were recorded at the current `mc_nerf_amd/csrc`
+digest (bench.py drops a stale file, which would leave the headline line without measured traffic)."""
+import glob
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _latest_default_line():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))
+    assert files, "no bench line under profiles/"
+    return files[-1], json.loads(open(files[-1]).read())
+
+
+def test_bench_line_contract():
+    path, d = _latest_default_line()
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert k in d and isinstance(d[k], t), (path, k)
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["dtype"].startswith("f16x3") and d["valid"] is True and d["skipped_optimizer_steps"] == 0
+    # value = rays of all ranks / max-over-ranks time
+    assert abs(d["value"] - d["config"]["rays_per_step_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == ("GB/s" if r["bound"] == "hbm" else "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert r["other_roof"]["bound"] != r["bound"] and r["frac"] >= r["other_roof"]["frac"]
+    if r["bound"] == "hbm":        # achieved = contract bytes per launch / the kernel's duration
+        assert abs(r["achieved"] - r["contract_bytes_per_launch"] / (r["ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        assert r["peak"] == 8000.0
+    assert r["traffic"] is not None and 0.98 < r["traffic"] / r["contract_bytes_per_launch"] < 1.05    # no wasted re-reads
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"] and c["unit"] == d["unit"]
+    assert d["parity"]["rgb_f_max_abs_err"] < 1e-4 and d["parity"]["rgb_c_max_abs_err"] < 1e-4
+    for p in ("f16", "bf16", "f32"):
+        assert d["by_precision"][p]["valid"] and d["by_precision"][p]["steps"] >= 20
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_pmc_traffic_belongs_to_the_sources_in_the_tree(precision):
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{precision}.json")))
+    assert rec["csrc_digest"] == bench.csrc_digest(), \
+        "profiles/pmc_traffic_*.json was recorded at other kernel sources: re-run scripts/pmc_bench.sh on the GPU box"
+    traffic, src = bench.pmc_traffic(precision, "mlp_dw<256>")
+    assert traffic and traffic > 1e9 and rec["csrc_digest"] in src
