@@ -337,15 +337,19 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     return rec, k_mean
 
 
+# the sources that define the MLP kernels whose traffic is recorded (everything they include)
+MLP_KERNEL_SOURCES = ("mcnerf_common.h", "mcnerf_kernels.h", "mcnerf_16.h", "mcnerf_x3.h", "mlp16_fwd.hip", "mlp16_bwd.hip", "mlp16_dw.hip",
+                      "mlp_x3_fwd.hip", "mlp_x3_bwd.hip", "mlp_x3_dw.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_dw.hip")
+
+
 def csrc_digest():
-    """Content digest of the kernel sources (the GPU box has no .git): a recorded profile belongs to the kernels it names."""
+    """Content digest of the MLP kernels' sources (the GPU box has no .git): a recorded profile belongs to the kernels it names."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "mc_nerf_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in sorted(MLP_KERNEL_SOURCES):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -257,6 +257,12 @@ int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* g
                       float* const* exp_avg_sq, const long long* sizes, float lr, float beta1, float beta2, float eps,
                       float weight_decay, float step_size, int rectified, uint32_t* guard, int phase, void* stream);
 
+/* Finish of the data-parallel step's ONE gradient all-reduce (mc_nerf_amd/distributed.py; replaces the bucketed reducer of
+ * DistributedDataParallel, /root/reference main.py:60-62): `arena` = [n_grad summed gradient floats | n_flags summed flags]
+ * after the SUM all-reduce.  One launch divides the gradients by `world` (DDP's average) and adds 1 to *asym when some rank's
+ * "produced a gradient" flags differ from this rank's `local_flags` (sum != world * local). */
+int mcnerf_sync_finish(float* arena, long long n_grad, int n_flags, int world, const float* local_flags, int32_t* asym, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

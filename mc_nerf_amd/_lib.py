@@ -40,6 +40,7 @@ SIGNATURES = {
     "mcnerf_sample_perm": (_I, [_P, ctypes.c_longlong, _I, _P, _P]),
     "mcnerf_mlp_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "mcnerf_encode_bwd": (_I, [_P, _P, _I, _P, _P, _P]),
+    "mcnerf_sync_finish": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "mcnerf_mlp_apply_save": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _P, _P]),
     "mcnerf_mlp_apply_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
     "mcnerf_mlp_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,

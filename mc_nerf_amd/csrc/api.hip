@@ -398,4 +398,9 @@ int mcnerf_radam_step(int n_tensors, float* const* params, const float* const* g
     return 0;
 }
 
+int mcnerf_sync_finish(float* arena, long long n_grad, int n_flags, int world, const float* local_flags, int32_t* asym, void* stream) {
+    REQ(arena && local_flags && asym && n_grad >= 0 && n_flags >= 0 && world >= 1, "mcnerf_sync_finish");
+    return check("mcnerf_sync_finish", mcn_launch_sync_finish(arena, n_grad, n_flags, (float)world, local_flags, (int*)asym, (hipStream_t)stream));
+}
+
 }  // extern "C"

@@ -78,6 +78,7 @@ struct McnDwArgs {
 hipError_t mcn_launch_dw(const McnDwArgs& a, hipStream_t st);
 
 hipError_t mcn_launch_pack(const McnLayout& lay, const float* params, float* packed, hipStream_t st);
+hipError_t mcn_launch_sync_finish(float* arena, long long n_grad, int n_flags, float world, const float* local, int* asym, hipStream_t st);
 
 struct McnCompositeArgs {
     const float* sig_rgb;     // [N,S,4]

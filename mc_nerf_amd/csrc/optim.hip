@@ -70,3 +70,23 @@ hipError_t mcn_launch_radam(const McnRadamTable& t, int n_blocks, unsigned* guar
     if (phase & 4) hipLaunchKernelGGL(radam_kernel, dim3(n_blocks), dim3(256), 0, st, t, guard, (phase & 8) ? 1 : 0);
     return hipGetLastError();
 }
+
+// ---- finish of the step's one gradient all-reduce (mc_nerf_amd/distributed.py, FlatGradSync.sync): the arena holds
+// [n_grad summed gradient floats | n_flags summed "this rank produced a gradient" flags].  One launch averages the gradients
+// (arena / world, the division DistributedDataParallel applies: /root/reference main.py:60-62 wraps the model in it) and checks
+// that every rank set the same flags (sum == world * local flag), counting a disagreeing step in *asym.
+__global__ __launch_bounds__(256) void sync_finish_kernel(float* arena, long long n_grad, int n_flags, float world, const float* local, int* asym) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_grad) arena[i] = arena[i] / world;
+    if (blockIdx.x == 0) {
+        int bad = 0;
+        for (int k = threadIdx.x; k < n_flags; k += blockDim.x) bad |= arena[n_grad + k] != local[k] * world;
+        bad = __syncthreads_or(bad);
+        if (bad && threadIdx.x == 0) atomicAdd(asym, 1);
+    }
+}
+hipError_t mcn_launch_sync_finish(float* arena, long long n_grad, int n_flags, float world, const float* local, int* asym, hipStream_t st) {
+    const long long blocks = (n_grad + 255) / 256;
+    hipLaunchKernelGGL(sync_finish_kernel, dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(256), 0, st, arena, n_grad, n_flags, world, local, asym);
+    return hipGetLastError();
+}

@@ -145,8 +145,14 @@ class FlatGradSync:
             local = self._flag_cache[key] = torch.tensor(have, dtype=torch.float32, device=self.arena.device)
         self.arena[self.n_grad:].copy_(local)
         dist.all_reduce(self.arena, op=dist.ReduceOp.SUM)     # the step's ONE collective
-        self.arena[:self.n_grad].div_(self.world)
-        if self.check_flags or key not in self._trusted:
+        trusted = not (self.check_flags or key not in self._trusted)
+        fused = trusted and self.arena.is_cuda                # average + flag check in one launch (mcnerf_sync_finish)
+        if fused:
+            from . import ops
+            ops.sync_finish(self.arena, self.n_grad, self.world, local, self._asym)
+        else:
+            self.arena[:self.n_grad].div_(self.world)
+        if not trusted:
             reduced = self.arena[self.n_grad:].tolist()       # (device -> host synchronisation)
             if all((r > 0) == (h > 0) and (r == 0 or r == self.world) for r, h in zip(reduced, have)):
                 self._trusted.add(key)
@@ -155,7 +161,7 @@ class FlatGradSync:
                 logging.warning("FlatGradSync: the ranks disagree on which parameters have gradients; reading the flags back every step from now on")
                 self.check_flags = True
             have = reduced
-        else:                                      # trusted pattern: same flags on every rank <=> reduced == world * local; count the steps where not
+        elif not fused:                            # trusted pattern: same flags on every rank <=> reduced == world * local; count the steps where not
             self._asym += (self.arena[self.n_grad:] != local * self.world).any().to(torch.int32)
         # A reduced slice becomes its parameter's gradient whenever a rank produced one (DDP semantics: a parameter unused
         # on this rank but used elsewhere still receives the averaged gradient, otherwise the replicas diverge -- with

@@ -236,6 +236,13 @@ def mlp_apply(net: Net, params: Tensor, packed: Tensor, x_enc: Tensor, dirs: Ten
     return out
 
 
+def sync_finish(arena: Tensor, n_grad: int, world: int, local_flags: Tensor, asym: Tensor) -> None:
+    """arena[:n_grad] /= world; asym += any(arena[n_grad:] != world * local_flags) -- the finish of FlatGradSync's one all-reduce
+    in one launch."""
+    _lib.call("mcnerf_sync_finish", _p(arena), int(n_grad), int(arena.numel() - n_grad), int(world), _p(local_flags),
+              _p(asym, torch.int32), _stream())
+
+
 def encode_bwd(x: Tensor, barf_w: Tensor, d_out: Tensor) -> Tensor:
     """Backward of `encode`: d_out [n,63] -> d_x [n,3]."""
     n = x.shape[0]
