@@ -18,7 +18,10 @@ HEADERS = ["mcnerf_common.h", "mcnerf_kernels.h", "mcnerf_16.h", "mcnerf_x3.h", 
 # their 256-wide instantiations run one wave per SIMD with 512 registers, where hipcc would otherwise put the MFMA
 # accumulators in AGPRs (every epilogue read then costs a v_accvgpr_read behind a full MFMA drain)
 FILE_FLAGS = {s: ["-mllvm", "-pragma-unroll-threshold=200000", "-mllvm", "-amdgpu-mfma-vgpr-form"] for s in ("mlp_x3_fwd.hip", "mlp_x3_bwd.hip")}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc's SLP vectoriser packs adjacent scalar fp32 multiplies / adds of the layer epilogues into v_pk_mul_f32 /
+# v_pk_add_f32, which cost more beside MFMAs than the scalar pairs they replace (MI355X_MICROARCH.md, issue-cost table); same-box A/B:
+# f16x3 saving forward 12.03 -> 11.60 ms (256-wide), 3.17 -> 3.08 (128-wide), 128-wide backward 2.99 -> 2.83 ms, results bit-identical
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _newer(a, b):
@@ -66,4 +69,4 @@ def build(force=False, verbose=True, extra_flags=(), tag=""):
 
 if __name__ == "__main__":
     tag = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), "")
-    build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a.startswith("-D")], tag=tag)
+    build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a.startswith("-") and not a.startswith("--")], tag=tag)
