@@ -73,6 +73,16 @@ __device__ __forceinline__ float mcnx3_val(unsigned hi, unsigned lo, int e) {
     const f16x2_t h = __builtin_bit_cast(f16x2_t, hi), l = __builtin_bit_cast(f16x2_t, lo);
     return (float)h[e] + (float)l[e];
 }
+// v - (float)(half HI ? 1 : 0 of the packed f16 word hw) in ONE instruction: v_fma_mix_f32 computes hw.half * (-1) + v with the
+// f16 source converted on the fly; the product is exact, so the single rounding is the subtraction's (bit-identical to
+// v_cvt_f32_f16 + v_sub_f32, one vector instruction less per element in the (hi, lo) split of every layer output).
+template <int HI>
+__device__ __forceinline__ float mcnx3_residual(float v, unsigned hw) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hw), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hw), "v"(v));
+    return r;
+}
 __device__ __forceinline__ float mcnx3_relu(float x) {       // integer max: no canonicalising v_max in front
     const int i = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, i > 0 ? i : 0);

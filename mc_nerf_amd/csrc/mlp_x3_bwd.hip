@@ -80,9 +80,7 @@ __device__ __forceinline__ void mcnx3_bwd_seg(Mcn16Ring& ring, char* smem, int l
                 wkeep = w;
                 outh[2 * t + (p >> 2)][p & 3] = MODE != 0 ? mcn16_pkmul(w, bits) : w;
             } else {
-                const f16x2_t hh = __builtin_bit_cast(f16x2_t, wkeep);
-                const f32x2_t back = __builtin_convertvector(hh, f32x2_t);
-                const unsigned w = Mcn16T<false>::pack(v0 - back[0], v1 - back[1]);
+                const unsigned w = Mcn16T<false>::pack(mcnx3_residual<0>(v0, wkeep), mcnx3_residual<1>(v1, wkeep));
                 outl[2 * t + (p >> 2)][p & 3] = MODE != 0 ? mcn16_pkmul(w, bits) : w;
             }
         } else {

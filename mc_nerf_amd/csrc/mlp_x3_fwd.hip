@@ -85,9 +85,7 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
                 wkeep = w;
                 outh[2 * t + (p >> 2)][p & 3] = w;
             } else if (ph == IPW - 1) {
-                const f16x2_t hh = __builtin_bit_cast(f16x2_t, wkeep);
-                const f32x2_t back = __builtin_convertvector(hh, f32x2_t);
-                outl[2 * t + (p >> 2)][p & 3] = Mcn16T<false>::pack(v0 - back[0], v1 - back[1]);
+                outl[2 * t + (p >> 2)][p & 3] = Mcn16T<false>::pack(mcnx3_residual<0>(v0, wkeep), mcnx3_residual<1>(v1, wkeep));
             } else {
                 if (SAVE) {
                     mb = (p == 0) ? mcn16_nz(wkeep) : ((mb << 1) | mcn16_nz(wkeep));
