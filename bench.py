@@ -32,6 +32,18 @@ sys.path.insert(0, ROOT)
 # algorithmic FLOPs per evaluated sample, forward: 2 x weight MACs.  The backward chain (dX) and the
 # weight gradients (dW) are one forward-equivalent each: a training step is 3x forward.
 F_FINE, F_COARSE = 2 * 629248, 2 * 101632
+
+
+def net_flops(net):
+    """2 x weight MACs of a (depth, width, [skip]) CorseFine_NeRF (model/net_block.py:40-65): forward FLOPs per sample."""
+    d, w, skips = net
+    macs = 63 * w + (d - 1) * w * w + sum(63 * w for k in skips if 0 < k < d) + (w * w + w) + (w * w + 27 * w)
+    return 2 * macs
+
+
+# SURVEY 8(d) "Bound": minimum HBM traffic of a step if activations never left the CU -- per ray o, d 24 B + gt 12 B + pixel id 8 B in,
+# rgb_c + rgb_f 24 B out (+ the composite's per-ray scalars) ~ 100 B, plus both nets' parameters and their gradients once.
+ALGO_BYTES_PER_RAY = 100
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0      # ibid., "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0              # ibid., "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
@@ -224,8 +236,47 @@ def parity_probe(precision, dev):
             "what": "train render of 256 rays, random-init cfg-2 nets, same draws, vs the fp32 CPU oracle"}
 
 
-def run_precision(precision, args, steps, warmup, rank, world, dev, timer, images_cache):
-    """Builds the cfg-2 model in `precision`, runs warmup + `steps` timed steps; returns the per-mode record."""
+def parse_net(text):
+    """'8x256x4' -> (8, 256, [4]) (depth x width x skip layer; config/config.yaml:76-81)."""
+    d, w, k = (int(t) for t in text.lower().split("x"))
+    return (d, w, [k])
+
+
+def calibrate_occupancy(model, step_nograd, target, n_grid):
+    """SURVEY 8(d) "occupancy control": shifts the coarse net's sigma-head bias until the selected fraction of the fine grid
+    (model/mc_nerf.py:619-632: `weights >= min(thresh, max)`, x `scale`) is `target`.  The fraction falls monotonically with
+    the bias below the random-init value (every alpha falls), so a bisection on the shift over no-grad renders of the bench's
+    own rays finds it; outside the timed region (it reads the count back).  Returns (shift, measured fraction)."""
+    import torch
+    bias = model.nerf.nerf_coarse.sigma[2].bias
+    base = bias.detach().clone()
+
+    def frac(shift):
+        with torch.no_grad():
+            bias.copy_(base + shift)
+            tot = 0.0
+            for i in range(3):
+                step_nograd(i)
+                tot += float(model.nerf.last_selection[1].item())
+        return tot / 3 / n_grid
+
+    lo, hi = -20.0, 0.0
+    if frac(hi) <= target:
+        return 0.0, frac(0.0)
+    for _ in range(14):
+        mid = 0.5 * (lo + hi)
+        if frac(mid) > target:
+            hi = mid
+        else:
+            lo = mid
+    shift = 0.5 * (lo + hi)
+    return shift, frac(shift)
+
+
+def run_precision(precision, args, steps, warmup, rank, world, dev, timer, images_cache, *, rays=None, samples=None, scale=None,
+                  coarse=None, occupancy=None):
+    """Builds the model in `precision` (cfg-2 shape unless overridden), runs warmup + `steps` timed steps; returns the per-mode
+    record.  `occupancy` = target selected fraction of the fine grid (None: random-init weights as they are)."""
     import torch
     import torch.distributed as dist
     from mc_nerf_amd import distributed as D
@@ -235,8 +286,11 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
 
     torch.manual_seed(42 + rank)                   # main.py:274-277: seed + rank
     H = W = args.img
-    sp = S.make_sys_param(dev, samples=args.samples, scale=args.scale, batch=args.rays, H=H, W=W, barf_mask=False,
-                          precision=precision, rig=args.rig)
+    rays = rays or args.rays
+    samples, scale = samples or args.samples, scale or args.scale
+    coarse = coarse or parse_net(args.coarse)
+    sp = S.make_sys_param(dev, samples=samples, scale=scale, batch=rays, H=H, W=W, barf_mask=False,
+                          precision=precision, rig=args.rig, coarse=coarse)
     model = MC_Model(sp).to(dev)
     S.init_cameras_near_gt(model, noise=1e-3)
     loss_fn = MC_NeRF_Loss(sp)
@@ -251,6 +305,12 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     wpts, pts, images = images_cache["wpts"], images_cache["pts"], images_cache["images"]
     cams = D.shard_cameras(C, 0, rank, world, seed=42)
     counts, ar_events = [], []
+    occ = None
+    if occupancy is not None:
+        def nograd_step(i):
+            model((images, torch.tensor([cams[i % len(cams)]]), wpts, pts, wpts, pts), 20, "GLOBAL_OPTIM_EPOCH", 0.6)
+        shift, got = calibrate_occupancy(model, nograd_step, occupancy, rays * samples * scale)
+        occ = {"target": occupancy, "sigma_bias_shift": shift, "selected_fraction_at_calibration": got}
 
     def step(i, timed):
         cam = cams[i % len(cams)]
@@ -310,10 +370,13 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     skipped = int(opt.skipped_steps())              # optimiser steps the overflow guard refused (inf / NaN gradients): must be 0
     k_mean = float(torch.stack(counts).float().mean())
     ks = timer.summary()
-    rec = {"precision": precision, "value": args.rays * world * steps / dt, "unit": "rays/s", "steps": steps,
-           "ms_per_step": dt / steps * 1e3, "fine_samples_per_ray": k_mean / args.rays, "finite": finite,
+    rec = {"precision": precision, "value": rays * world * steps / dt, "unit": "rays/s", "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "rays_per_step_per_gpu": rays, "fine_samples_per_ray": k_mean / rays,
+           "selected_fraction": k_mean / (rays * samples * scale), "finite": finite,
            "skipped_optimizer_steps": skipped, "valid": bool(finite and skipped == 0),
            "kernel_ms": {f"mlp_{k}<{w}>": v for (k, w), v in sorted(ks.items())}}
+    if occ is not None:
+        rec["occupancy"] = occ
     if world > 1:
         rec["allreduce_ms"] = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
         rec["params_identical_across_ranks"] = in_sync
@@ -330,7 +393,9 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
             per_call[f"mlp_{k}<256>"] = {"ms": ms, "mfma_TFLOPs": tf, "mfma_frac": tf / mfma_peak, "contract_bytes_per_launch": contract[k] * k_mean,
                                          "hbm_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS}
     rec["per_call"] = per_call
-    rec["step_algorithmic_tflop"] = 3 * (F_FINE * k_mean + F_COARSE * args.rays * args.samples) / 1e12
+    rec["step_algorithmic_tflop"] = 3 * (F_FINE * k_mean + net_flops(coarse) * rays * samples) / 1e12
+    n_param = sum(p.numel() for p in model.parameters())
+    rec["algorithmic_bytes_per_step"] = ALGO_BYTES_PER_RAY * rays + 2 * 4 * n_param
     rec["step_mfma_frac"] = rec["step_algorithmic_tflop"] / (dt / steps) / mfma_peak
     del model, opt, sync
     torch.cuda.empty_cache()
@@ -379,6 +444,19 @@ def pmc_traffic(precision, kernel_key):
     return None, None
 
 
+def pmc_step_traffic(precision):
+    """Sum of the PMC-measured HBM bytes of all six MLP kernels of a step from the same committed recording (None when stale)."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{precision}.json")
+    if not os.path.isfile(path):
+        return None, None
+    rec = json.load(open(path))
+    if rec.get("csrc_digest") != csrc_digest():
+        return None, None
+    # (one launch per step each: fwd / bwd / dW of the coarse and of the fine net; everything else moves < 0.1 % of a step's bytes)
+    tot = sum(v["hbm_bytes_per_launch"] for k, v in rec.get("kernels", {}).items() if "mlp" in k or "dw" in k)
+    return (tot or None), path
+
+
 def run_rank(args):
     import torch
     import torch.distributed as dist
@@ -412,27 +490,51 @@ def run_rank(args):
     others = {}
     for p in [q for q in args.also.split(",") if q and q != args.precision]:
         others[p], _ = run_precision(p, args, max(20, args.steps // 5), 3, rank, world, dev, timer, cache)
+    slim = lambda r: {k: v for k, v in r.items() if k not in ("per_call",)}
+    # ---- SURVEY 8(d) "Synthetic inputs": the same step with the selected fraction of the fine grid pinned (sigma-head bias of the
+    # coarse net shifted; K reported with each), in the headline mode and in f16; and the "coarse also 8x256/[4]" variant
+    by_occ, extra = {}, {}
+    sub_steps = max(20, args.steps // 2)
+    default_shape = (args.rays == 32768 and args.samples == 64 and args.scale == 2 and args.img == 800 and args.coarse == "4x128x2")
+    if args.occupancy:
+        for rho in [float(t) for t in args.occupancy.split(",") if t]:
+            by_occ[f"{rho:g}"] = {p: slim(run_precision(p, args, sub_steps, 3, rank, world, dev, timer, cache, occupancy=rho)[0])
+                                 for p in dict.fromkeys([args.precision, "f16"])}
+    if args.extra and default_shape:
+        ex = lambda **kw: slim(run_precision(args.precision, args, sub_steps, 3, rank, world, dev, timer, cache, **kw)[0])
+        extra["coarse_8x256x4"] = dict(ex(coarse=(8, 256, [4])), what="both nets 8x256/[4] (SURVEY 8: the variant reported beside the default); "
+                                       "kernel_ms<256> averages the coarse and the fine call")
+        extra["rays_7000"] = dict(ex(rays=7000), what="N = 7000, the reference's `batch` (config/config.yaml:30)")
+        extra["reference_default_128x5_rays_7000"] = dict(ex(rays=7000, samples=128, scale=5),
+                                                          what="the reference's default sampling: 128 coarse x 5 (fine grid 640, random cap at 128 kept per ray), N = 7000")
+        if world == 1:
+            rargs = argparse.Namespace(**dict(vars(args), steps=3))
+            r = run_render(rargs, rank, world, dev)
+            extra["render"] = {"value": r["value"], "unit": r["unit"], "ms_per_image": r["ms_per_step"], "images": r["steps"],
+                               "what": r["metric"] + ", " + r["config"]["workload"]}
     if rank == 0:
         pc = head["per_call"]
-        # The dominant KERNEL is the longest single launch.  In the register-chain modes (f16x3, f16, bf16) every fine-net call
-        # is one launch and the weight-gradient kernel is the longest; in f32 mlp_dw is 15 launches per call (aggregate in
-        # `per_call`) and the longest launch is a chain.  `roofline` prices that kernel against the roof that BINDS it (the
-        # larger of its two fractions): the weight-gradient kernel streams its GEMM operands once and is HBM-bound -- achieved =
-        # contract (algorithmic) bytes per launch / its duration, `traffic` = the PMC-measured bytes -- the chains are MFMA-bound
-        # (algorithmic FLOPs against the dense f16 peak).  The other roof of the same kernel sits in `other_roof`.
-        single = pc if args.precision != "f32" else {k: v for k, v in pc.items() if k != "mlp_dw<256>"}
+        # the path is MFMA-bound by construction (> 10^6 FLOP per algorithmic byte), so `roofline` prices the dominant
+        # kernel -- the longest single launch -- by its ALGORITHMIC FLOPs (2 x weight MACs per evaluated sample; the three MFMAs per
+        # product of the split-f16 mode and any recomputation are not counted) over its HIP-event duration against the dense f16
+        # MFMA peak (fp32 MFMA peak in the exact-fp32 mode).  What the kernel's own design moves through HBM (its contract bytes:
+        # the saved operands of the weight-gradient GEMMs) is in `other_roof`, with the PMC-measured bytes as `traffic`; the bytes a
+        # step would move if activations never left the CU are `algorithmic_bytes_per_step`.
+        single = pc if args.precision != "f32" else {k: v for k, v in pc.items() if k != "mlp_dw<256>"}    # (f32: mlp_dw is 15 launches)
         dom = max(single, key=lambda k: single[k]["ms"])
         mfma_peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
-        traffic, tsrc = pmc_traffic(args.precision, dom) if args.rays == 32768 else (None, None)
+        traffic, tsrc = pmc_traffic(args.precision, dom) if default_shape else (None, None)
+        step_traffic, _ = pmc_step_traffic(args.precision) if default_shape else (None, None)
         hbm_roof = {"bound": "hbm", "achieved": pc[dom]["hbm_GBs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": pc[dom]["hbm_frac"],
+                    "what": "the kernel's CONTRACT bytes (saved GEMM operands it is designed to move; not algorithmic) / duration",
                     "contract_bytes_per_launch": pc[dom]["contract_bytes_per_launch"],
                     "pmc_over_contract": (traffic / pc[dom]["contract_bytes_per_launch"]) if traffic else None}
-        mfma_roof = {"bound": "mfma", "achieved": pc[dom]["mfma_TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s", "frac": pc[dom]["mfma_frac"]}
-        first, second = (hbm_roof, mfma_roof) if pc[dom]["hbm_frac"] > pc[dom]["mfma_frac"] else (mfma_roof, hbm_roof)
-        roof = {"bound": first["bound"], "kernel": dom, "ms": pc[dom]["ms"], "achieved": first["achieved"], "peak": first["peak"],
-                "unit": first["unit"], "frac": first["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                "traffic_source": tsrc, "contract_bytes_per_launch": hbm_roof["contract_bytes_per_launch"],
-                "pmc_over_contract": hbm_roof["pmc_over_contract"], "other_roof": second,
+        roof = {"bound": "mfma", "kernel": dom, "ms": pc[dom]["ms"], "achieved": pc[dom]["mfma_TFLOPs"], "peak": mfma_peak,
+                "unit": "TFLOP/s", "frac": pc[dom]["mfma_frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                "traffic_source": tsrc, "other_roof": hbm_roof,
+                "algorithmic_bytes_per_step": head["algorithmic_bytes_per_step"],
+                "step_traffic_bytes": step_traffic,
+                "traffic_over_algorithmic": (step_traffic / head["algorithmic_bytes_per_step"]) if step_traffic else None,
                 "per_call": pc, "step_algorithmic_tflop": head["step_algorithmic_tflop"], "step_mfma_frac": head["step_mfma_frac"]}
         out = {
             "metric": "train rays/sec (coarse+fine, 64+128 samples)", "value": head["value"], "unit": "rays/s",
@@ -440,19 +542,24 @@ def run_rank(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
             "config": {"workload": workload_text(args), "precision": args.precision, "rays_per_step_per_gpu": args.rays,
-                       "fine_samples_per_ray": head["fine_samples_per_ray"],
+                       "fine_samples_per_ray": head["fine_samples_per_ray"], "selected_fraction": head["selected_fraction"],
                        "parallelism": f"dp{world} (cameras sharded, 1 flat all-reduce/step)"},
             "roofline": roof,
+            "kernel_ms": head["kernel_ms"],
             "by_precision": {p: {k: v for k, v in r.items() if k != "precision"} for p, r in others.items()},
+            "by_occupancy": by_occ,
+            "extra_lines": extra,
         }
-        for k in ("allreduce_ms", "params_identical_across_ranks", "asymmetric_grad_steps", "finite", "skipped_optimizer_steps", "valid"):
+        for k in ("allreduce_ms", "rank_ms_per_step", "params_identical_across_ranks", "asymmetric_grad_steps", "finite", "skipped_optimizer_steps", "valid"):
             if k in head:
                 out[k] = head[k]
         if world == 1 and not args.no_cpu_baseline:
             out["parity"] = parity_probe(args.precision, dev)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-        bad = [p for p, r in [(args.precision, head)] + list(others.items()) if not r["valid"]]
+        allrecs = [(args.precision, head)] + list(others.items()) + [(f"occupancy {o}/{p}", r) for o, d in by_occ.items() for p, r in d.items()] \
+            + [(k, r) for k, r in extra.items() if "valid" in r]
+        bad = [p for p, r in allrecs if not r["valid"]]
         if bad:                 # a mode whose steps were skipped by the overflow guard (or went non-finite) measured nothing
             print(f"bench.py: INVALID measurement in mode(s) {bad}: non-finite parameters or optimiser steps skipped", file=sys.stderr)
             if world > 1:
@@ -517,6 +624,10 @@ def main():
     ap.add_argument("--scale", type=int, default=2, help="fine grid = samples x scale (config `scale`; reference default 5), capped at 128 kept per ray")
     ap.add_argument("--img", type=int, default=800, help="image side (BASELINE cfg 5: 1600)")
     ap.add_argument("--rig", default="ball", choices=["ball", "array", "halfball", "room"], help="camera rig of the synthetic scene")
+    ap.add_argument("--coarse", default="4x128x2", help="coarse net depth x width x skip (config/config.yaml:76-78); 8x256x4 = SURVEY 8's second variant")
+    ap.add_argument("--occupancy", default="0.25,0.05", help="selected fractions of the fine grid measured beside the random-init line "
+                    "(by_occupancy; sigma-head bias shift, SURVEY 8(d)); empty = none")
+    ap.add_argument("--no-extra", dest="extra", action="store_false", help="skip extra_lines (8x256 coarse, N = 7000, 128x5, render)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16", "bf16"],
                     help="MFMA mode of the MLP kernels: split-f16 f16x3 (fp32-grade, the headline: the reference computes in fp32) or "

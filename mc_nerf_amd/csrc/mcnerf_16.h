@@ -150,6 +150,14 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
+// The per-launch gradient scale of the reduced-precision backward / weight-gradient kernels: the power of two that puts
+// max|d_out| (a device word written by composite_bwd) near 2^4.  The exponent is clamped so that a tiny but non-zero
+// maximum (below ~2^-96) cannot overflow the scale to +inf (1 / SG would be 0 and every dY inf / NaN); the backward and
+// the weight-gradient kernel MUST agree on SG, so both call this.
+__device__ __forceinline__ float mcn16_grad_scale(float gmax) {
+    return (gmax > 0.f && gmax < 3e38f) ? exp2f(fminf(4.f - ceilf(log2f(gmax)), 100.f)) : 1.f;
+}
+
 // channel of contraction position (k-step s, lane half h, element j)
 __host__ __device__ __forceinline__ constexpr int mcn16_chan(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
     // gradient scale: a power of two that puts max|d_out| of the launch near 2^4 (4096x headroom below the f16 maximum
     // for growth through the layers); bf16 has fp32's range but shares the arithmetic
     const float gmax = __uint_as_float(*a.gmax_bits);
-    const float sg = (gmax > 0.f && gmax < 3e38f) ? exp2f(4.f - ceilf(log2f(gmax))) : 1.f;
+    const float sg = mcn16_grad_scale(gmax);
     const float inv_sg = 1.0f / sg;
     __syncthreads();
 

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES) void dwx3_stream_kernel(DwX3Job j
     const int ntiles = (rows + 31) / 32;
     if (ntiles <= 0) return;
     const float gmax = gmax_bits ? __uint_as_float(*gmax_bits) : 1.f;
-    const float sgs = (gmax > 0.f && gmax < 3e38f) ? exp2f(4.f - ceilf(log2f(gmax))) : 1.f;
+    const float sgs = mcn16_grad_scale(gmax);
     auto pieces = [](int shape) { return shape == 0 ? 2 * W / 16 : shape == 1 ? W / 16 + MCN16_ENCKS : shape == 2 ? 2 + W / 16 : 2 * W / 16 + MCN16_ENCKS; };
     long long total = 0;
     for (int s = 0; s < job.n; ++s) total += (long long)pieces(job.shape[s]) * ntiles;

@@ -142,7 +142,14 @@ class NeRF_Model(nn.Module):
     def inference(self, model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render=None, coarse=True, *, eps=None):
         """Reference :682-727.  Differentiable like the reference's: when autograd is recording and any input or parameter
         requires a gradient the pass runs on the stand-alone differentiable kernels (`_inference_general`: EncodeFn, MlpApplyFn,
-        composites in tensor ops); otherwise on the fused forward-only path (`_inference`)."""
+        composites in tensor ops); otherwise on the fused forward-only path (`_inference`).
+
+        DISPATCH, explicitly: the differentiable path is taken whenever grad mode is on and ANY of `xyz`, `rays_d`, `z_vals` or
+        the net's parameters requires a gradient -- i.e. always for a training-mode model called outside `torch.no_grad()`.
+        That path computes in exact fp32 whatever `precision` the model was built with, ignores `coarse`, and keeps
+        (depth + 2) * rows * width floats of saved activations: it exists for API parity (a caller differentiating through
+        `inference` directly), not for rendering.  Render under `torch.no_grad()` (as `render_rays_test`, `valid_train` and the
+        demo path do) to get the fused kernels in the configured precision; training goes through `render_rays_train`."""
         if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad
                                            for t in (xyz, rays_d, z_vals, *model.parameters())):
             return self._inference_general(model, embedding_xyz, step_r, xyz, rays_d, z_vals.float(), idx_render, eps)

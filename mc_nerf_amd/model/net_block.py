@@ -57,8 +57,8 @@ class MlpApplyFn(torch.autograd.Function):
     def backward(ctx, d_out):
         flat, dd, out = ctx.saved_tensors
         grads = torch.zeros_like(flat) if ctx.needs_input_grad[3] else None
+        # (ctx.save stays until autograd frees the node: a second backward through a retained graph works like the reference's)
         d_x, d_dirs = ops.mlp_apply_bwd(ctx.net, flat, ctx.packed, dd, out, d_out.reshape(-1, 4).float().contiguous(), ctx.save, grads)
-        ctx.save = None
         return (None, d_x.reshape(ctx.shapes[0]) if ctx.needs_input_grad[1] else None,
                 d_dirs.reshape(ctx.shapes[1]) if ctx.needs_input_grad[2] else None, grads)
 

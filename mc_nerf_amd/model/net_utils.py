@@ -73,10 +73,11 @@ class RAdam(Optimizer):
         for i, b in enumerate(buckets):
             first.setdefault(b[0][0].device, i)
             last[b[0][0].device] = i
+        tables = [self._bucket_tables(ps) for ps, _, _, _ in buckets]          # (built once: both passes use the same pointer tables)
         for i, (ps, group, n_sma, ss) in enumerate(buckets):
-            self._step_fused(ps, group, n_sma, ss, phase=(1 if first[ps[0].device] == i else 0) | 2)
+            self._step_fused(ps, group, n_sma, ss, phase=(1 if first[ps[0].device] == i else 0) | 2, tables=tables[i])
         for i, (ps, group, n_sma, ss) in enumerate(buckets):
-            self._step_fused(ps, group, n_sma, ss, phase=4 | (8 if last[ps[0].device] == i else 0))
+            self._step_fused(ps, group, n_sma, ss, phase=4 | (8 if last[ps[0].device] == i else 0), tables=tables[i])
         return loss
 
     def skipped_steps(self) -> int:
@@ -106,7 +107,9 @@ class RAdam(Optimizer):
                 p.add_(p, alpha=-wd * lr)
             p.add_(m, alpha=-step_size * lr)
 
-    def _step_fused(self, ps, group, n_sma, step_size, phase=15):
+    def _bucket_tables(self, ps):
+        """The device-pointer tables of one fused launch: parameters, gradients, both moments, sizes (+ the gradient tensors
+        they point into, kept alive until the step's last launch)."""
         n = len(ps)
         PtrArr, SizeArr = ctypes.c_void_p * n, ctypes.c_longlong * n
         grads = []
@@ -121,6 +124,11 @@ class RAdam(Optimizer):
                 PtrArr(*[self.state[p]["exp_avg"].data_ptr() for p in ps]),
                 PtrArr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in ps]),
                 SizeArr(*[p.numel() for p in ps]))
+        return args, grads
+
+    def _step_fused(self, ps, group, n_sma, step_size, phase=15, tables=None):
+        n = len(ps)
+        args, _keep = tables if tables is not None else self._bucket_tables(ps)
         beta1, beta2 = group["betas"]
         dev = ps[0].device
         if dev not in self._guard:

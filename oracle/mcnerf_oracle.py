@@ -231,6 +231,8 @@ def render_rays_train(pc: Dict[str, Tensor], pf: Dict[str, Tensor], cfg: RenderC
     jitter [N,1] ~ U(0,(far-near)/Sc) (:600); eps_c, eps_sel [N,Sc] and eps_f [N,Sf] are the
     three N(0,1) draws of sigma2weights (:719 coarse, :619 selection, :719 fine);
     cap_perm is the CPU randperm of :631 (only used when K > N*128).
+    idx_override [K,2], when given, IS the kept (ray, fine sample) list of :625-632 -- selection and cap already applied by
+    the caller (the HIP path's device-side list restricted to a ray subset): the fine pass renders exactly those samples.
     Returns dict(rgb_c, rgb_f, depth_c, sig_c, w_sel, idx_f, out_c, out_f).
     """
     N = rays_d.shape[0]
@@ -243,7 +245,7 @@ def render_rays_train(pc: Dict[str, Tensor], pf: Dict[str, Tensor], cfg: RenderC
     with torch.no_grad():
         w_sel = sigma2weights(deltas_of(z_c), sig_c.detach(), eps_sel)
         idx_f = select_fine(w_sel, cfg) if idx_override is None else idx_override
-        if idx_f.shape[0] > N * cfg.max_fine_per_ray:
+        if idx_override is None and idx_f.shape[0] > N * cfg.max_fine_per_ray:
             idx_f = idx_f[cap_perm[: N * cfg.max_fine_per_ray]]
     z_f = zf.unsqueeze(0).expand(N, -1) + jitter
     rgb_f, _, _, _, out_f = inference(pf, cfg.fine, cfg, step_r, rays_o, rays_d, z_f, eps_f, idx_render=idx_f)

@@ -336,8 +336,17 @@ def g12_radam():
     npz("g12_radam_loss", **arrs)
 
 
+def g7_full_size():
+    """cfg-2 nets at size: 2048 rays through 4x128 + 8x256 (BASELINE.md measured the reference at this size), forward + backward of
+    the actual reference; rgb, loss, ray gradients, and of each of the 40 parameter gradients the norm + every 97th element."""
+    g7_train("g7_train_s64x2_full2048", O.RenderCfg(samples=64, scale=2), 2048, 75, 1.0)
+
+
 def main():
     torch.set_num_threads(4)
+    if "--only-full-size" in sys.argv:
+        return g7_full_size()
+    g7_full_size()
     g11_mc_model_step()
     g11_mc_model_step("CAM_PARAM_EPOCH", "g11b_mc_model_cam_param", extr_shift=0.7)
     g11_mc_model_step("FINE_TUNE_EPOCH", "g11c_mc_model_fine_tune")

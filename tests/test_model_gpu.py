@@ -82,6 +82,52 @@ def test_render_rays_train_matches_reference(gpu_device, name, precision):
     assert checked == len(list(m.nerf_coarse.parameters())) + len(list(m.nerf_fine.parameters()))
 
 
+# per mode: (rgb abs, gradient error relative to each tensor's max |reference gradient|)
+FULL_TOL = {"f32": (1e-4, 1e-4), "f16x3": (1e-4, 1e-4), "f16": (5e-5, 2e-2), "bf16": (4e-4, 1e-1)}
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
+def test_full_size_gradient_golden(gpu_device, precision):
+    """The at-size gradient pin: cfg-2 nets (coarse 4x128 + fine 8x256), 2048 rays, forward + backward of the ACTUAL reference
+    (tests/golden/make_golden.py: g7_full_size; 0.2 M fine samples) -- rgb, loss, the ray gradients and, of each of the 40
+    parameter gradients, every 97th element and the norm.  f32 / f16x3: 1e-4 abs on rgb and 1e-4 of each tensor's largest
+    reference gradient (no max(1, .) floor: the gradients of a 2048-ray mean are small); identical selection.  f16 / bf16:
+    their operand rounding, gated at ~3x what they measure here (printed)."""
+    from mc_nerf_amd.model import MC_NeRF_Loss
+    g = load_golden("g7_train_s64x2_full2048")
+    dev = gpu_device
+    m, cfg, pc, pf = build_model(g, dev, precision=precision)
+    assert (cfg.coarse.depth, cfg.coarse.width, cfg.fine.depth, cfg.fine.width) == (4, 128, 8, 256) and g["rays_d"].shape[0] == 2048
+    d = t(g["rays_d"]).to(dev).requires_grad_(True)
+    o = t(g["rays_o"]).to(dev).requires_grad_(True)
+    rgb_c, rgb_f = m.render_rays_train(d, o, 0, float(g["step_r"]), jitter=t(g["jitter"]).to(dev), eps_c=t(g["eps_c"]).to(dev),
+                                       eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
+    tol_rgb, tol_g = FULL_TOL[precision]
+    loss = MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([rgb_c, rgb_f, t(g["gt"]).to(dev)])
+    loss.backward()
+    e_rgb = max(err(rgb_c, g["rgb_c"]), err(rgb_f, g["rgb_f"]))
+    rel = lambda a, ref: err(a, ref) / float(np.abs(ref).max())
+    worst, worst_key = max((rel(d.grad, g["d_rays_d"]), "d_rays_d"), (rel(o.grad, g["d_rays_o"]), "d_rays_o"))
+    worst_norm, checked = 0.0, 0
+    for tag, net in (("c", m.nerf_coarse), ("f", m.nerf_fine)):
+        for k_, p in net.named_parameters():
+            if f"g{tag}.{k_}" in g:
+                e = rel(p.grad, g[f"g{tag}.{k_}"])
+            else:
+                e = rel(p.grad.reshape(-1)[::97], g[f"gsamp{tag}.{k_}"])
+                n_ref = float(g[f"gnorm{tag}.{k_}"])
+                worst_norm = max(worst_norm, abs(float(p.grad.norm()) - n_ref) / n_ref)
+            if e > worst:
+                worst, worst_key = e, f"{tag}.{k_}"
+            checked += 1
+    assert checked == 40
+    k = int(m.last_selection[1].item())
+    print(f"[{precision}] 2048 rays, {k} fine samples vs the reference's golden: max|rgb| {e_rgb:.1e}, |loss| {abs(float(loss) - float(g['loss'])):.1e}, "
+          f"worst gradient {worst:.1e} of its tensor's max ({worst_key}), worst norm {worst_norm:.1e}")
+    assert e_rgb < tol_rgb and abs(float(loss) - float(g["loss"])) < 1e-5
+    assert worst < tol_g and worst_norm < 10 * tol_g, worst_key
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_render_coarse_only(gpu_device, precision):
     """BASELINE cfg 1's path: render_rays_train(only_coarse=True) (model/mc_nerf.py:598, 611-612) forward AND backward against
@@ -347,23 +393,27 @@ def test_valid_train_renders_the_checkpoint_just_saved(gpu_device, tmp_path, pre
     assert float(val["psnr"]) > 0.0 and os.path.exists(os.path.join(model.nerf.train_img_pth, model.nerf.data_name, "epoch_3.png"))
 
 
-RIG_CASES = [("array", 800, 64, 2, "f16x3"), ("halfball", 800, 64, 2, "f16x3"), ("room", 800, 64, 2, "f16x3"),     # BASELINE cfg 3, cfg 4, (cfg 5's rig)
-             ("room", 1600, 64, 4, "bf16"), ("array", 1600, 64, 4, "bf16")]                                           # cfg 5: 1600 x 1600, fine grid 256, bf16
+RIG_CASES = [("array", 800, 64, 2, "f16x3", 4096), ("halfball", 800, 64, 2, "f16x3", 4096), ("room", 800, 64, 2, "f16x3", 4096),     # BASELINE cfg 3, cfg 4, (cfg 5's rig)
+             ("room", 1600, 64, 4, "bf16", 4096), ("array", 1600, 64, 4, "bf16", 4096),                              # cfg 5: 1600 x 1600, fine grid 256, bf16
+             ("room", 1600, 64, 4, "f16x3", 4096),                                                                    # ... the cap path in the fp32-grade mode
+             ("room", 1600, 64, 4, "bf16", 32768), ("room", 1600, 64, 4, "f16x3", 32768)]                            # ... at the bench's batch size
 
 
-@pytest.mark.parametrize("rig,H,samples,scale,precision", RIG_CASES)
-def test_rig_configs_one_global_optim_step(gpu_device, rig, H, samples, scale, precision):
+@pytest.mark.parametrize("rig,H,samples,scale,precision,N", RIG_CASES)
+def test_rig_configs_one_global_optim_step(gpu_device, rig, H, samples, scale, precision, N):
     """BASELINE.json configs[2..4] at their geometry: the Array (C = 100, synthetic_dataset_code/Array.py:176-191), HalfBall
     (C = 100, HalfBall.py:162-178) and Room (C = 88, Room.py:171-180) rigs, 800 x 800 with 64 x 2 sampling in the fp32-grade
     mode and 1600 x 1600 (2.56 M pixel ids through sample_perm / raygen / gather_gt) with 64 x 4 sampling in bf16, where the
-    random cap of model/mc_nerf.py:630-632 binds.  One GLOBAL_OPTIM step of MC_Model at N = 4096 rays with full-size nets
-    (the model draws its own pixel subset on the device); a 128-ray subset (same pixel ids, same draws) goes through the CPU
-    oracle: rays, ground truth, coarse render -- and the fine render where the cap does not interfere."""
+    random cap of model/mc_nerf.py:630-632 binds (also in the fp32-grade mode and at the bench's 32768 rays).  One GLOBAL_OPTIM
+    step of MC_Model at N rays with full-size nets (the model draws its own pixel subset on the device); a 128-ray subset (same
+    pixel ids, same draws) goes through the CPU oracle: rays, ground truth, coarse render, and -- with the device's kept
+    (ray, sample) list restricted to the subset as the oracle's `idx_override` -- the fine render and the gradients of the loss
+    with respect to the subset's ray origins and directions through both nets, cap or no cap."""
     from mc_nerf_amd import synthetic as S
     from mc_nerf_amd.data import DeviceImageSet
     from mc_nerf_amd.model import MC_Model, MC_NeRF_Loss
     dev = gpu_device
-    W, N, n_sub = H, 4096, 128
+    W, n_sub = H, 128
     Sf = samples * scale
     sp = S.make_sys_param(dev, samples=samples, scale=scale, batch=N, H=H, W=W, barf_mask=False, precision=precision, rig=rig)
     torch.manual_seed(21)
@@ -385,7 +435,12 @@ def test_rig_configs_one_global_optim_step(gpu_device, rig, H, samples, scale, p
         return seen["pix"]
     model.sample_pixels = pix_and_record
     orig = model.nerf.render_rays_train
-    model.nerf.render_rays_train = lambda d, o, e, r, only_coarse=False: orig(d, o, e, r, only_coarse, **draws)
+
+    def render_and_record(d, o, e, r, only_coarse=False):
+        d.retain_grad(), o.retain_grad()                   # (the rays are RaygenFn outputs: keep their gradients for the subset check)
+        seen["d"], seen["o"] = d, o
+        return orig(d, o, e, r, only_coarse, **draws)
+    model.nerf.render_rays_train = render_and_record
     loss_dict, _, _, _ = model((images, torch.tensor([cam]), wpts.to(dev), pts.to(dev), wpts.to(dev), pts.to(dev)), 20, "GLOBAL_OPTIM_EPOCH", 0.6)
     loss = MC_NeRF_Loss(sp)(loss_dict, "GLOBAL_OPTIM_EPOCH")
     loss.backward()
@@ -416,18 +471,37 @@ def test_rig_configs_one_global_optim_step(gpu_device, rig, H, samples, scale, p
     assert float((gt[sub] - gt_ref).abs().max()) < 1e-6
     cfg = O.RenderCfg(samples=samples, scale=scale, barf_mode=True, barf_start=sp["barf_start"], barf_end=sp["barf_end"])
     dr = {k_: v.cpu()[sub] for k_, v in draws.items()}
-    with torch.no_grad():
-        r = O.render_rays_train(pc, pf, cfg, d_ref, o_ref, 0.6, dr["jitter"], dr["eps_c"], dr["eps_sel"], dr["eps_f"],
-                                cap_perm=torch.arange(n_sub * Sf) if capped else None)     # (any subset: only rgb_c is compared when the cap binds)
+    # The kept (ray, fine sample) list is the DEVICE's: selection threshold min(1e-3, max w) is a batch quantity and the cap keeps a
+    # random N * 128 of the whole batch's selection (model/mc_nerf.py:623-632), so the subset's rows of that list -- renumbered to
+    # the subset -- are what the oracle's fine pass renders (`idx_override`); the coarse pass and the selection weights need nothing.
+    idx_dev = model.nerf.last_selection[0][:k].cpu().long()
+    where = torch.full((N,), -1, dtype=torch.long)
+    where[sub] = torch.arange(n_sub)
+    rows = where[idx_dev[:, 0]] >= 0
+    idx_sub = torch.stack([where[idx_dev[rows, 0]], idx_dev[rows, 1]], -1)
+    order = torch.argsort(idx_sub[:, 0] * Sf + idx_sub[:, 1])                   # (nonzero order: ray-major, then sample)
+    idx_sub = idx_sub[order]
+    assert idx_sub.shape[0] > 0 and torch.unique(idx_sub[:, 0] * Sf + idx_sub[:, 1]).numel() == idx_sub.shape[0]
+    d_leaf, o_leaf = d_ref.clone().requires_grad_(True), o_ref.clone().requires_grad_(True)
+    r = O.render_rays_train(pc, pf, cfg, d_leaf, o_leaf, 0.6, dr["jitter"], dr["eps_c"], dr["eps_sel"], dr["eps_f"], idx_override=idx_sub)
+    if not capped:                                        # without the cap the oracle's own selection must be the device's
+        own = O.select_fine(r["w_sel"], cfg)
+        thr_binds = float(r["w_sel"].max()) >= cfg.weight_thresh
+        assert not thr_binds or torch.equal(own, idx_sub)
+    # the batch's loss restricted to the subset: both MSE terms average over all N * 3 elements (model/loss.py:33-43)
+    (((r["rgb_c"] - gt_ref) ** 2).sum() / (3 * N) + ((r["rgb_f"] - gt_ref) ** 2).sum() / (3 * N)).backward()
     tol = {"f16x3": 1e-4, "bf16": 4e-4}[precision]
-    ec = float((rgb_c[sub] - r["rgb_c"]).abs().max())
-    msg = f"[{rig} {H}x{W} {samples}x{scale} {precision}] C = {C}, {k} fine samples, subset of {n_sub}: max|rgb_c - oracle| {ec:.1e}"
-    assert ec < tol, msg
-    if not capped:
-        ef = float((rgb_f[sub] - r["rgb_f"]).abs().max())
-        msg += f", max|rgb_f - oracle| {ef:.1e}"
-        assert ef < tol, msg
+    tol_g = {"f16x3": 1e-4, "bf16": 5e-2}[precision]      # (gradients: relative to the subset's largest; bf16 operands are 8-bit)
+    ec = float((rgb_c[sub] - r["rgb_c"].detach()).abs().max())
+    ef = float((rgb_f[sub] - r["rgb_f"].detach()).abs().max())
+    gd_, go_ = seen["d"].grad.cpu()[sub], seen["o"].grad.cpu()[sub]
+    eg_d = float((gd_ - d_leaf.grad).abs().max() / d_leaf.grad.abs().max())
+    eg_o = float((go_ - o_leaf.grad).abs().max() / o_leaf.grad.abs().max())
+    msg = (f"[{rig} {H}x{W} {samples}x{scale} {precision}] C = {C}, {k} fine samples ({'cap binds' if capped else 'no cap'}), subset of {n_sub} "
+           f"({idx_sub.shape[0]} kept): max|rgb_c - oracle| {ec:.1e}, max|rgb_f - oracle| {ef:.1e}, d_rays_d {eg_d:.1e}, d_rays_o {eg_o:.1e} (relative)")
     print(msg)
+    assert ec < tol and ef < tol, msg
+    assert eg_d < tol_g and eg_o < tol_g, msg
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f16"])
