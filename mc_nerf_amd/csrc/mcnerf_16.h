@@ -154,8 +154,11 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 // max|d_out| (a device word written by composite_bwd) near 2^4.  The exponent is clamped so that a tiny but non-zero
 // maximum (below ~2^-96) cannot overflow the scale to +inf (1 / SG would be 0 and every dY inf / NaN); the backward and
 // the weight-gradient kernel MUST agree on SG, so both call this.
+#ifndef MCN16_SG_LOG2
+#define MCN16_SG_LOG2 4.f             // max|d_out| * SG lands in (2^(SG_LOG2 - 1), 2^SG_LOG2]
+#endif
 __device__ __forceinline__ float mcn16_grad_scale(float gmax) {
-    return (gmax > 0.f && gmax < 3e38f) ? exp2f(fminf(4.f - ceilf(log2f(gmax)), 100.f)) : 1.f;
+    return (gmax > 0.f && gmax < 3e38f) ? exp2f(fminf(MCN16_SG_LOG2 - ceilf(log2f(gmax)), 100.f)) : 1.f;
 }
 
 // channel of contraction position (k-step s, lane half h, element j)

@@ -162,7 +162,10 @@ __device__ unsigned long long g_mcnx3_fstamps[2 * 64 * 16];
 extern "C" int mcnerf_debug_stamps_x3_fwd(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mcnx3_fstamps), sizeof(g_mcnx3_fstamps));
 }
-#define MCNX3_FSTAMP(i) do { if (W == 256 && blockIdx.x < 64 && pass == (long long)blockIdx.x + 20ll * gridDim.x && lane == 0 && wave == 0) \
+#ifndef MCNX3_STAMP_W
+#define MCNX3_STAMP_W 256
+#endif
+#define MCNX3_FSTAMP(i) do { if (W == MCNX3_STAMP_W && blockIdx.x < 64 && pass == (long long)blockIdx.x + 20ll * gridDim.x && lane == 0 && wave == 0) \
         g_mcnx3_fstamps[((SAVE ? 64 : 0) + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MCNX3_FSTAMP(i) do { } while (0)

@@ -278,6 +278,37 @@ def rgb_loss(rgb_c: Tensor, rgb_f: Optional[Tensor], gt: Tensor) -> Tensor:
     return loss
 
 
+def permute_hidden_units(p: Dict[str, Tensor], net: NetCfg, seed: int):
+    """The same network function (model/net_block.py:67-78) with every hidden layer's units enumerated in another order (rows of
+    the producing layer, matching input columns of its consumers).  fp32 arithmetic is not invariant under it -- sums run in
+    another order, a pre-activation within a rounding of zero takes the other side of its ReLU -- so evaluating the path on
+    both is a measurement of the reference arithmetic's own noise (the tolerance floor of at-size gradient comparisons).
+    -> (state dict, un-permute function for a dict of gradients keyed like the state dict)"""
+    gen = torch.Generator().manual_seed(seed)
+    q = {k: v.clone() for k, v in p.items()}
+    D, W = net.depth, net.width
+    plan = []                                              # (producer keys, [(consumer key, column offset)], perm)
+    for l in range(1, D + 1):
+        cons = [f"xyz_encoding_{l + 1}.0.weight"] if l < D else ["sigma.0.weight", "sh.0.weight"]
+        plan.append(([f"xyz_encoding_{l}.0.weight", f"xyz_encoding_{l}.0.bias"], cons, torch.randperm(W, generator=gen)))
+    for head in ("sigma", "sh"):
+        plan.append(([f"{head}.0.weight", f"{head}.0.bias"], [f"{head}.2.weight"], torch.randperm(W, generator=gen)))
+
+    def apply(d, inverse):
+        out = {k: v.clone() for k, v in d.items()}
+        for prod, cons, pm in plan:
+            ix = torch.argsort(pm) if inverse else pm
+            for k in prod:
+                out[k] = out[k][ix]
+            for c in cons:
+                off = out[c].shape[1] - W                  # (the skip layer's input is [x_enc(63), h])
+                w = out[c].clone()
+                w[:, off:] = out[c][:, off:][:, ix]
+                out[c] = w
+        return out
+    return apply(q, False), (lambda grads: apply(grads, True))
+
+
 # --------------------------------------------------------------------------- cameras / rays
 def get_rays(pose: Tensor, intr_inv: Tensor, H: int, W: int):
     """MC_Model.get_rays for ONE camera (model/mc_nerf.py:124-145, 213-256).

@@ -338,8 +338,48 @@ def g12_radam():
 
 def g7_full_size():
     """cfg-2 nets at size: 2048 rays through 4x128 + 8x256 (BASELINE.md measured the reference at this size), forward + backward of
-    the actual reference; rgb, loss, ray gradients, and of each of the 40 parameter gradients the norm + every 97th element."""
-    g7_train("g7_train_s64x2_full2048", O.RenderCfg(samples=64, scale=2), 2048, 75, 1.0)
+    the actual reference; rgb, loss, ray gradients, and of each of the 40 parameter gradients the norm + every 97th element.
+
+    Also the REFERENCE'S OWN fp32 noise at this size: the same step with nothing changed but the order in which the hidden units
+    of every layer are enumerated (an identical function; sgemm then adds in another order, and pre-activations within a
+    rounding of zero take the other side of a ReLU).  Per tensor, the difference between the two runs relative to the tensor's
+    largest gradient (`noise_max.*`) and in relative L2 (`noise_l2.*`): what "agrees with the reference" can mean at size."""
+    tag, cfg, n, seed = "g7_train_s64x2_full2048", O.RenderCfg(samples=64, scale=2), 2048, 75
+    g7_train(tag, cfg, n, seed, 1.0)
+
+    def run(permute):
+        m = NeRF_Model(sys_param(cfg))
+        pc, pf = O.init_params(cfg.coarse, seed + 100), O.init_params(cfg.fine, seed + 200)
+        undo = (lambda g_: g_, lambda g_: g_)
+        if permute:
+            (pc, uc), (pf, uf) = O.permute_hidden_units(pc, cfg.coarse, 1), O.permute_hidden_units(pf, cfg.fine, 2)
+            undo = (uc, uf)
+        m.nerf_coarse.load_state_dict(pc)
+        m.nerf_fine.load_state_dict(pf)
+        d, o = make_rays(n, seed)
+        d.requires_grad_(True), o.requires_grad_(True)
+        gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(seed + 7))
+        torch.manual_seed(seed)
+        rgb_c, rgb_f = m(d, o, 0, 1.0)
+        MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([rgb_c, rgb_f, gt]).backward()
+        out = {"d_rays_d": d.grad, "d_rays_o": o.grad, "rgb_c": rgb_c.detach(), "rgb_f": rgb_f.detach()}
+        for t_, net, un in (("c", m.nerf_coarse, undo[0]), ("f", m.nerf_fine, undo[1])):
+            for k, v in un({k: p.grad for k, p in net.named_parameters()}).items():
+                out[f"{t_}.{k}"] = v
+        return out
+    a, b = run(False), run(True)
+    path = os.path.join(HERE, tag + ".npz")
+    z = dict(np.load(path))
+    assert np.array_equal(z["rgb_c"], a["rgb_c"].numpy()) and np.array_equal(z["d_rays_d"], a["d_rays_d"].numpy())   # the fixture's run, repeated
+    for k in a:
+        if k.startswith("rgb"):
+            z["noise_abs." + k] = float((a[k] - b[k]).abs().max())
+        else:
+            z["noise_max." + k] = float((a[k] - b[k]).abs().max() / a[k].abs().max())
+            z["noise_l2." + k] = float((a[k] - b[k]).double().norm() / a[k].double().norm())
+    np.savez_compressed(path, **z)
+    worst = max((float(v), k) for k, v in z.items() if k.startswith("noise_max."))
+    print(f"reference's own reorder noise at {n} rays: worst {worst[0]:.1e} of its tensor's max ({worst[1][10:]}), rgb {z['noise_abs.rgb_f']:.1e}")
 
 
 def main():
