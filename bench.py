@@ -297,6 +297,7 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     opt = RAdam(model.parameters(), lr=5e-4, weight_decay=4e-4)
     sync = D.FlatGradSync(model, world)
     sync.broadcast_parameters()
+    model.nerf.reserve_workspaces(rays)              # the kernels' workspaces are sized here, once, and re-used by every step
     C = model.train_numb
     if "wpts" not in images_cache:
         wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0])
@@ -344,6 +345,8 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     t0 = time.perf_counter()
     for i in range(steps):                          # the timed region: nothing but the steps
         step(warmup + i, True)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0             # this rank's own completion (before it waits for the others): a straggler shows here
     barrier()
     dt = time.perf_counter() - t0
     # per-kernel launch durations (HIP events on the launch stream around the three fine / coarse MLP calls): a separate,
@@ -378,6 +381,13 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     if occ is not None:
         rec["occupancy"] = occ
     if world > 1:
+        mine = torch.tensor([dt_local / steps * 1e3, sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))], device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = torch.stack(every).cpu()
+        rec["rank_ms_per_step"] = {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max()), "all": [round(float(v), 3) for v in per_rank[:, 0]],
+                                   "what": "each rank's own completion time of the timed steps / steps, before the closing barrier"}
+        rec["rank_allreduce_ms"] = {"min": float(per_rank[:, 1].min()), "max": float(per_rank[:, 1].max())}
         rec["allreduce_ms"] = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
         rec["params_identical_across_ranks"] = in_sync
         rec["asymmetric_grad_steps"] = sync.asymmetric_steps()      # ranks disagreeing on which tensors have gradients: must be 0
@@ -550,7 +560,7 @@ def run_rank(args):
             "by_occupancy": by_occ,
             "extra_lines": extra,
         }
-        for k in ("allreduce_ms", "rank_ms_per_step", "params_identical_across_ranks", "asymmetric_grad_steps", "finite", "skipped_optimizer_steps", "valid"):
+        for k in ("allreduce_ms", "rank_ms_per_step", "rank_allreduce_ms", "params_identical_across_ranks", "asymmetric_grad_steps", "finite", "skipped_optimizer_steps", "valid"):
             if k in head:
                 out[k] = head[k]
         if world == 1 and not args.no_cpu_baseline:
@@ -561,7 +571,9 @@ def run_rank(args):
             + [(k, r) for k, r in extra.items() if "valid" in r]
         bad = [p for p, r in allrecs if not r["valid"]]
         if bad:                 # a mode whose steps were skipped by the overflow guard (or went non-finite) measured nothing
-            print(f"bench.py: INVALID measurement in mode(s) {bad}: non-finite parameters or optimiser steps skipped", file=sys.stderr)
+            from mc_nerf_amd import ops
+            print(f"bench.py: INVALID measurement in mode(s) {bad}: non-finite parameters or optimiser steps skipped; weight tensors "
+                  f"outside their mode's operand range: {ops.range_report() or 'none'}", file=sys.stderr)
             if world > 1:
                 dist.destroy_process_group()
             sys.exit(3)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MCNERF_ABI_VERSION 4
+#define MCNERF_ABI_VERSION 5
 
 int mcnerf_abi_version(void);
 const char* mcnerf_last_error(void);
@@ -139,8 +139,11 @@ int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows
  * Packed weights are two fragment STREAMS (forward order, backward = transposed order); workspaces are
  * fragment-major and sized by mcnerf_ws_bytes_16 (capacity is rounded up to whole 256-row passes inside). */
 long long mcnerf_packed_bytes_16(int depth, int width, int skip, int dtype, int backward);
+/* range_flags (may be NULL): depth + 3 words, one per packed weight tensor in state-dict order (trunk layers 0 .. depth-1,
+ * sigma.0, sh.0, sh.2); word t is OR-ed with 1 when tensor t holds a weight outside the mode's operand range (f16: |w| > 65504,
+ * f16x3: |w| > 65504 / 2^8 = 255.9, any mode: not finite).  Sticky: zero the words once, read them when a step was refused. */
 int mcnerf_pack_weights_16(int depth, int width, int skip, const float* params, void* packed_fwd, void* packed_bwd,
-                           int dtype, void* stream);
+                           int dtype, uint32_t* range_flags, void* stream);
 /* which: 0 = activations or pre-activation gradients (all depth+2 slots), 1 = encodings, 2 = ReLU bit masks (all slots),
  *        3 = d(sh.2 outputs / sigma_raw), 4 = sh.2 outputs */
 long long mcnerf_ws_bytes_16(int depth, int width, int dtype, long long capacity, int which);
@@ -235,8 +238,11 @@ int mcnerf_reproj_loss_bwd(const float* pd, const float* gt, int n, int H, int W
  * gradients in one launch:  total = L_intr / (L_intr + 1e-8) [normalise != 0: the GLOBAL_OPTIM / FINE_TUNE rescaling of :20-23, its
  * denominator a detached constant; normalise == 0: L_intr itself] + mean((rgb_c - gt)^2) + mean((rgb_f - gt)^2) [rgb_f may be null:
  * coarse only, :37-41].  pd, pt_gt [np,2] pixels (np may be 0), rgb_*, gt [nrgb] floats (nrgb = 3 N).
- * out[3] = {total, L_intr, rgb term};  d_pd [np,2], d_c, d_f [nrgb] = d total / d input.
+ * out[MCNERF_TRAIN_LOSS_OUT]: out[0..2] = {total, L_intr, rgb term}; out[3] is an arrival counter that must be ZERO on entry (it
+ * is zero again on exit, so one zero-initialised buffer serves every call) and out[4..] per-block partial sums -- the value is
+ * added in block order, i.e. deterministic;  d_pd [np,2], d_c, d_f [nrgb] = d total / d input.
  * mcnerf_scale3: a, b, c (c may be null) *= *g in place -- the saved gradients times the upstream gradient of the total. */
+#define MCNERF_TRAIN_LOSS_OUT 132
 int mcnerf_train_loss(const float* pd, const float* pt_gt, int np, int H, int W, int normalise,
                       const float* rgb_c, const float* rgb_f, const float* gt, int nrgb,
                       float* out, float* d_pd, float* d_c, float* d_f, void* stream);

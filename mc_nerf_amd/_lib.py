@@ -15,7 +15,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MCNERF_LIB selects another build of the SAME library (kernel ablation / tuning variants, scripts/ablate.sh)
 LIB_PATH = os.environ.get("MCNERF_LIB") or os.path.join(_HERE, "libmcnerf.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _P = c_void_p
 _I = c_int
@@ -47,7 +47,7 @@ SIGNATURES = {
                             _P, _P, _P, _P, _P]),
     "mcnerf_mlp_dw": (_I, [_I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P]),
     "mcnerf_packed_bytes_16": (_L, [_I, _I, _I, _I, _I]),
-    "mcnerf_pack_weights_16": (_I, [_I, _I, _I, _P, _P, _P, _I, _P]),
+    "mcnerf_pack_weights_16": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "mcnerf_ws_bytes_16": (_L, [_I, _I, _I, _L, _I]),
     "mcnerf_mlp_fwd_16": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
     "mcnerf_mlp_bwd_16": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,

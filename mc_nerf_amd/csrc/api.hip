@@ -211,10 +211,10 @@ long long mcnerf_packed_bytes_16(int depth, int width, int skip, int dtype, int 
     return (long long)(backward ? mcn16_bwd_stream(L) : mcn16_fwd_stream(L)).total_frags * 1024;
 }
 int mcnerf_pack_weights_16(int depth, int width, int skip, const float* params, void* packed_fwd, void* packed_bwd,
-                           int dtype, void* stream) {
+                           int dtype, uint32_t* range_flags, void* stream) {
     REQ(net_ok(depth, width, skip) && params && packed_fwd && packed_bwd && dtype_ok(dtype), "mcnerf_pack_weights_16");
-    if (dtype == 2) return check("mcnerf_pack_weights_16", mcnx3_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, (hipStream_t)stream));
-    return check("mcnerf_pack_weights_16", mcn16_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, dtype, (hipStream_t)stream));
+    if (dtype == 2) return check("mcnerf_pack_weights_16", mcnx3_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, range_flags, (hipStream_t)stream));
+    return check("mcnerf_pack_weights_16", mcn16_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, dtype, range_flags, (hipStream_t)stream));
 }
 static size_t slot_bytes_of(int dtype, long long capacity, int width) { return dtype == 2 ? mcnx3_slot_bytes(capacity, width) : mcn16_slot_bytes(capacity, width); }
 long long mcnerf_ws_bytes_16(int depth, int width, int dtype, long long capacity, int which) {

@@ -246,39 +246,61 @@ hipError_t mcn_launch_reproj_loss_bwd(const float* pd, const float* gt, int n, i
 // and its gradients wrt the reprojected pixels and the two renders, in ONE launch of one workgroup (two block reductions,
 // then the gradient pass): ~ 10 tiny elementwise / reduce launches of the eager formulation each way.  out[0] = total,
 // out[1] = L_intr, out[2] = the rgb term.
-__global__ __launch_bounds__(1024) void train_loss_kernel(const float* pd, const float* ptg, int np, float inv_w2, float inv_h2, int normalise,
-                                                         const float* rgb_c, const float* rgb_f, const float* gt, int nrgb,
-                                                         float* out, float* d_pd, float* d_c, float* d_f) {
-    __shared__ float red[2][1024];
+// Grid of <= MCN_LOSS_BLOCKS blocks: every block writes its slice of the rgb gradients (they do not depend on any sum: d rgb =
+// 2 (rgb - gt) / nrgb) and its partial of the squared error to out[4 + block]; the block that arrives last (counter in out[3],
+// zero on entry, zero again on exit) adds the partials IN BLOCK ORDER (a deterministic value), evaluates the reprojection
+// term of the few calibration points, and writes out[0..2] and d_pd.  (One block of 1024 threads took 108 us at 32768 rays.)
+__global__ __launch_bounds__(256) void train_loss_kernel(const float* pd, const float* ptg, int np, float inv_w2, float inv_h2, int normalise,
+                                                        const float* rgb_c, const float* rgb_f, const float* gt, int nrgb,
+                                                        float* out, float* d_pd, float* d_c, float* d_f) {
+    __shared__ float red[256];
+    __shared__ int last;
     const int t = threadIdx.x;
-    float ai = 0.f, ar = 0.f;
-    for (int i = t; i < np; i += 1024) {
+    const float gr = 2.f / (float)nrgb;
+    float ar = 0.f;
+    for (int i = blockIdx.x * 256 + t; i < nrgb; i += gridDim.x * 256) {
+        const float g = gt[i], ec = rgb_c[i] - g;
+        ar += ec * ec;
+        d_c[i] = gr * ec;
+        if (rgb_f) { const float ef = rgb_f[i] - g; ar += ef * ef; d_f[i] = gr * ef; }
+    }
+    red[t] = ar;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[4 + blockIdx.x] = red[0];
+        __threadfence();
+        last = atomicAdd(reinterpret_cast<unsigned*>(out + 3), 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float ai = 0.f;
+    for (int i = t; i < np; i += 256) {
         const float ex = pd[2 * i] - ptg[2 * i], ey = pd[2 * i + 1] - ptg[2 * i + 1];
         ai += ex * ex * inv_w2 + ey * ey * inv_h2;
     }
-    for (int i = t; i < nrgb; i += 1024) {
-        const float g = gt[i], ec = rgb_c[i] - g;
-        ar += ec * ec;
-        if (rgb_f) { const float ef = rgb_f[i] - g; ar += ef * ef; }
-    }
-    red[0][t] = ai; red[1][t] = ar;
+    red[t] = ai;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (t < s) { red[0][t] += red[0][t + s]; red[1][t] += red[1][t + s]; }
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
         __syncthreads();
     }
-    const float li = np > 0 ? red[0][0] / (float)np : 0.f, lr = red[1][0] / (float)nrgb;
+    float sum = 0.f;
+    for (int b = 0; b < (int)gridDim.x; ++b) sum += __builtin_nontemporal_load(out + 4 + b);       // (block order: deterministic)
+    const float li = np > 0 ? red[0] / (float)np : 0.f, lr = sum / (float)nrgb;
     const float si = normalise ? 1.0f / (li + 1e-8f) : 1.0f;       // d total / d L_intr
-    if (t == 0) { out[0] = li * si + lr; out[1] = li; out[2] = lr; }
-    const float gi = si * 2.f / (float)(np > 0 ? np : 1), gr = 2.f / (float)nrgb;
-    for (int i = t; i < np; i += 1024) {
+    if (t == 0) {
+        out[0] = li * si + lr; out[1] = li; out[2] = lr;
+        *reinterpret_cast<unsigned*>(out + 3) = 0u;
+    }
+    const float gi = si * 2.f / (float)(np > 0 ? np : 1);
+    for (int i = t; i < np; i += 256) {
         d_pd[2 * i] = gi * (pd[2 * i] - ptg[2 * i]) * inv_w2;
         d_pd[2 * i + 1] = gi * (pd[2 * i + 1] - ptg[2 * i + 1]) * inv_h2;
-    }
-    for (int i = t; i < nrgb; i += 1024) {
-        const float g = gt[i];
-        d_c[i] = gr * (rgb_c[i] - g);
-        if (rgb_f) d_f[i] = gr * (rgb_f[i] - g);
     }
 }
 // in place: the saved gradients times the upstream scalar (1 for loss.backward())
@@ -291,7 +313,10 @@ __global__ __launch_bounds__(256) void scale3_kernel(float* a, int na, float* b,
 }
 hipError_t mcn_launch_train_loss(const float* pd, const float* ptg, int np, int H, int W, int normalise, const float* rgb_c, const float* rgb_f,
                                  const float* gt, int nrgb, float* out, float* d_pd, float* d_c, float* d_f, hipStream_t st) {
-    hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(1024), 0, st, pd, ptg, np, 1.0f / ((float)W * (float)W), 1.0f / ((float)H * (float)H),
+    int blocks = (nrgb + 1023) / 1024;
+    if (blocks > MCN_LOSS_BLOCKS) blocks = MCN_LOSS_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(train_loss_kernel, dim3(blocks), dim3(256), 0, st, pd, ptg, np, 1.0f / ((float)W * (float)W), 1.0f / ((float)H * (float)H),
                        normalise, rgb_c, rgb_f, gt, nrgb, out, d_pd, d_c, d_f);
     return hipGetLastError();
 }

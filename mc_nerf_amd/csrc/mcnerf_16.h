@@ -140,7 +140,7 @@ struct Mcn16DwArgs {
     const unsigned* gmax_bits;
 };
 hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st);
-hipError_t mcn16_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, int bf16, hipStream_t st);
+hipError_t mcn16_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, int bf16, unsigned* range_flags, hipStream_t st);
 
 #ifdef __HIPCC__
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));

@@ -26,6 +26,7 @@ struct McnMlpFwdArgs {
 hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, float* out, hipStream_t st);
 hipError_t mcn_launch_encode_bwd(const float* x, const float* barf_w, int n, const float* d_out, float* d_x, hipStream_t st);
 hipError_t mcn_launch_sample_perm(long long* out, long long n, int batch, const unsigned* seed, hipStream_t st);
+#define MCN_LOSS_BLOCKS 128          // (include/mcnerf.h: MCNERF_TRAIN_LOSS_OUT = 4 + MCN_LOSS_BLOCKS floats of `out`)
 hipError_t mcn_launch_train_loss(const float* pd, const float* ptg, int np, int H, int W, int normalise, const float* rgb_c, const float* rgb_f,
                                  const float* gt, int nrgb, float* out, float* d_pd, float* d_c, float* d_f, hipStream_t st);
 hipError_t mcn_launch_scale3(float* a, int na, float* b, int nb, float* c, int nc, const float* g, hipStream_t st);

@@ -55,7 +55,7 @@ static inline size_t mcnx3_dsh_bytes(long long capacity) { return 2 * mcn16_dsh_
 hipError_t mcnx3_launch_fwd(const Mcn16FwdArgs& a, hipStream_t st);
 hipError_t mcnx3_launch_bwd(const Mcn16BwdArgs& a, hipStream_t st);
 hipError_t mcnx3_launch_dw(const Mcn16DwArgs& a, hipStream_t st);
-hipError_t mcnx3_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, hipStream_t st);
+hipError_t mcnx3_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, unsigned* range_flags, hipStream_t st);
 
 #ifdef __HIPCC__
 typedef float f32x2_t __attribute__((ext_vector_type(2)));

@@ -4,8 +4,19 @@
 // reads nn.Linear.weight directly, model/net_block.py:69-74).
 #include "mcnerf_16.h"
 
+// Range watch (both kernels): a weight whose 16-bit image is not finite -- |w| > 65504 in f16, |w| 2^8 > 65504 in the split-f16
+// mode, a non-finite w in any mode -- raises word `segment index` of `flags` (forward stream only: segment s IS packed weight
+// tensor s: trunk layers 0 .. D-1, sigma.0, sh.0, sh.2).  Sticky: the caller zeroes the words once and reads them when the
+// optimiser's guard has refused a step, so that "skipped step" becomes "tensor X is out of the mode's range".
+__device__ __forceinline__ void mcn16_range_watch(const float (&v)[8], float limit, unsigned* flags, int seg) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j])) + (v[j] != v[j] ? __builtin_inff() : 0.f);
+    if (!(m <= limit)) atomicOr(flags + seg, 1u);
+}
+
 template <bool BF>
-__global__ void pack16_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __restrict__ params, char* __restrict__ pf, char* __restrict__ pb) {
+__global__ void pack16_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __restrict__ params, char* __restrict__ pf, char* __restrict__ pb, unsigned* flags) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nf = sf.total_frags * 64, nb = sb.total_frags * 64;
     if (gid >= nf + nb) return;
@@ -35,25 +46,26 @@ __global__ void pack16_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __res
                 v[j] = sg.transposed ? params[p.src + (size_t)c * p.ld + p.col0 + o] : params[p.src + (size_t)o * p.ld + p.col0 + c];
         }
     }
+    if (flags && !bwd) mcn16_range_watch(v, BF ? 3.0e38f : 65504.f, flags, s);
     u32x4_t w;
 #pragma unroll
     for (int d = 0; d < 4; ++d) w[d] = Mcn16T<BF>::pack(v[2 * d], v[2 * d + 1]);
     *reinterpret_cast<u32x4_t*>((bwd ? pb : pf) + (size_t)id * 16) = w;
 }
 
-hipError_t mcn16_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, int bf16, hipStream_t st) {
+hipError_t mcn16_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, int bf16, unsigned* flags, hipStream_t st) {
     const Mcn16Stream sf = mcn16_fwd_stream(L), sb = mcn16_bwd_stream(L);
     const int total = (sf.total_frags + sb.total_frags) * 64;
     const int threads = 256, grid = (total + threads - 1) / threads;
-    if (bf16) hipLaunchKernelGGL(pack16_kernel<true>, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd);
-    else hipLaunchKernelGGL(pack16_kernel<false>, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd);
+    if (bf16) hipLaunchKernelGGL(pack16_kernel<true>, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd, flags);
+    else hipLaunchKernelGGL(pack16_kernel<false>, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd, flags);
     return hipGetLastError();
 }
 
 // ---- split-f16 ("f16x3") streams (mcnerf_x3.h): per logical fragment the hi piece (f16(w SW)) then the lo piece
 //      (f16(w SW - hi)), segments padded to whole slabs of 8 logical fragments.
 #include "mcnerf_x3.h"
-__global__ void packx3_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __restrict__ params, char* __restrict__ pf, char* __restrict__ pb) {
+__global__ void packx3_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __restrict__ params, char* __restrict__ pf, char* __restrict__ pb, unsigned* flags) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nf = sf.total_frags * 64, nb = sb.total_frags * 64;
     if (gid >= nf + nb) return;
@@ -83,6 +95,7 @@ __global__ void packx3_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __res
                 v[j] = sg.transposed ? params[p.src + (size_t)c * p.ld + p.col0 + o] : params[p.src + (size_t)o * p.ld + p.col0 + c];
         }
     }
+    if (flags && !bwd) mcn16_range_watch(v, 65504.f / MCNX3_SW, flags, s);
     u32x4_t wh, wl;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -95,10 +108,10 @@ __global__ void packx3_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __res
     *reinterpret_cast<u32x4_t*>(dst + 1024) = wl;
 }
 
-hipError_t mcnx3_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, hipStream_t st) {
+hipError_t mcnx3_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, unsigned* flags, hipStream_t st) {
     const Mcn16Stream sf = mcnx3_fwd_stream(L), sb = mcnx3_bwd_stream(L);
     const int total = (sf.total_frags + sb.total_frags) * 64;
     const int threads = 256, grid = (total + threads - 1) / threads;
-    hipLaunchKernelGGL(packx3_kernel, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd);
+    hipLaunchKernelGGL(packx3_kernel, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd, flags);
     return hipGetLastError();
 }

@@ -73,6 +73,7 @@ class NeRF_Model(nn.Module):
         self.last_flat_grads = None
         self.grad_arena = None            # set per step by distributed.FlatGradSync.prepare()
         self.grad_arena_used = False
+        self.ws_pool = None               # render.WorkspacePool: the kernels' saved-operand / gradient workspaces, re-used from step to step
         if self.mode != 0:
             self.nerf_ckpt_name = sys_param["demo_ckpt"]
             ckpt = torch.load(Path(self.nerf_ckpt_name), map_location=self.device)
@@ -137,6 +138,17 @@ class NeRF_Model(nn.Module):
             eps_f = torch.randn(N, self.samples_f, device=dev)
         return render_test(self, model_coarse, model_fine, rays_d.float(), rays_o.float(),
                            self._dev(eps_c).contiguous(), self._dev(eps_sel).contiguous(), self._dev(eps_f).contiguous(), _prepared)
+
+    def reserve_workspaces(self, n_rays: int):
+        """Sizes the training workspaces of both nets for `n_rays`-ray steps now (they are re-used from step to step afterwards:
+        render.WorkspacePool), so that the first timed / synchronised step of a multi-GPU run allocates nothing."""
+        from .render import _cap_needed, _pool
+        dev, st, pool = self.z_vals_c.device, self.settings, _pool(self)
+        rows_f = n_rays * (st.max_fine_per_ray if _cap_needed(st) else st.samples_f)
+        for net, rows in ((self.nerf_coarse.net, n_rays * st.samples_c), (self.nerf_fine.net, rows_f)):
+            save = pool.take_save(net, rows, dev, st.precision)
+            pool.give_grad(net, save, st.precision, pool.take_grad(net, save, st.precision))
+            pool.give_save(net, save, st.precision)
 
     # ------------------------------------------------------------------ per-pass API of the reference (:682-736)
     def inference(self, model, embedding_xyz, step_r, xyz, rays_d, z_vals, idx_render=None, coarse=True, *, eps=None):

@@ -142,6 +142,24 @@ class CorseFine_NeRF(nn.Module):
                                 nn.Linear(self.width, 3 * (self.deg + 1) ** 2))
         self._flat = None
         self._offsets = None
+        self._range_flags = {}
+        self.net_type = key
+
+    def weight_names(self) -> List[str]:
+        """The weight tensors that go through the 16-bit packing, in stream order (csrc/mcnerf_16.h: mcn16_fwd_stream)."""
+        return [f"xyz_encoding_{i + 1}.0.weight" for i in range(self.depth)] + ["sigma.0.weight", "sh.0.weight", "sh.2.weight"]
+
+    def range_flags(self, precision: str, device):
+        """Sticky per-tensor "weight outside the operand range of `precision`" words, filled by the packing kernel (None in
+        f32, which has no range to exceed): what RAdam.raise_on_overflow() names when the overflow guard has refused steps."""
+        if not ops.is16(precision):
+            return None
+        key = (precision, str(device))
+        if key not in self._range_flags:
+            f = torch.zeros(self.depth + 3, dtype=torch.int32, device=device)
+            self._range_flags[key] = f
+            ops.range_watch_register(f, f"{self.net_type} net", self.weight_names(), precision)
+        return self._range_flags[key]
 
     # ------------------------------------------------------------------ flat storage
     def ordered_parameters(self) -> List[nn.Parameter]:

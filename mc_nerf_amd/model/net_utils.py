@@ -86,10 +86,21 @@ class RAdam(Optimizer):
         return int(sum(int(g[1].item()) for g in self._guard.values()))
 
     def raise_on_overflow(self):
+        """Raises if the guard has refused steps, NAMING the weight tensors that left their precision mode's operand range
+        (the packing kernels flag them per tensor: ops.range_report); with every weight in range it is an activation or a
+        gradient that overflowed (f16: 65504; f16x3: activations 8188)."""
         n = self.skipped_steps()
         if n:
-            raise _lib.McnerfError(f"{n} optimiser step(s) skipped: non-finite gradients (operand range of the 16-bit / split-f16 "
-                                   "precision modes exceeded -- switch `precision` to 'f32' or lower the learning rate)")
+            from .. import ops
+            bad = ops.range_report()
+            if bad:
+                why = "weights outside the operand range of their precision mode: " + "; ".join(
+                    f"{label} {name} (mode {prec}: {ops.RANGE_TEXT[prec]})" for label, name, prec in bad)
+            else:
+                why = ("every packed weight is inside its mode's range, so an activation or a gradient overflowed the 16-bit operand "
+                       "format (f16: 65504; f16x3: |activation| < 8188)")
+            raise _lib.McnerfError(f"{n} optimiser step(s) skipped: non-finite gradients -- {why}.  Switch `precision` to 'f32' or "
+                                   "lower the learning rate / add weight decay")
 
     @staticmethod
     def _step_host(p, g, st, group, n_sma, step_size):

@@ -37,6 +37,50 @@ class RenderSettings:
         return self.samples_c * self.scale
 
 
+class WorkspacePool:
+    """The MLP kernels' saved-operand and gradient workspaces (up to ~46 GB per step at 32768 rays in the split-f16 mode), sized
+    ONCE per (net, row capacity, precision) and handed from step to step instead of going through the allocator every forward /
+    backward: RenderTrainFn.forward takes a set, .backward gives it back after the weight-gradient kernel has been enqueued
+    (stream order makes the re-use safe: the next forward's stores are behind that kernel).  A forward whose backward never
+    runs simply keeps its set (garbage-collected with the graph); a second forward before the first backward gets a fresh one.
+    `NeRF_Model.reserve_workspaces(n_rays)` fills the pool before the first step (multi-GPU: no first-step allocation in any
+    rank between two barriers)."""
+    MAX_KEYS = 6
+
+    def __init__(self):
+        self.free = {}
+
+    def _key(self, kind, net, capacity, device, precision):
+        return (kind, net.triple, int(capacity), str(device), precision)
+
+    def _take(self, key, make):
+        lst = self.free.get(key)
+        return lst.pop() if lst else make()
+
+    def _give(self, key, ws):
+        if key not in self.free and len(self.free) >= self.MAX_KEYS:
+            self.free.pop(next(iter(self.free)))            # (a changing shape -- test paths -- must not pin memory for ever)
+        self.free.setdefault(key, []).append(ws)
+
+    def take_save(self, net, capacity, device, precision):
+        return self._take(self._key("save", net, max(int(capacity), 1), device, precision), lambda: ops.alloc_save(net, capacity, device, precision=precision))
+
+    def give_save(self, net, save, precision):
+        self._give(self._key("save", net, save.capacity, save.act.device, precision), save)
+
+    def take_grad(self, net, save, precision):
+        return self._take(self._key("grad", net, save.capacity, save.act.device, precision), lambda: ops.alloc_grad_ws(net, save, precision))
+
+    def give_grad(self, net, save, precision, ws):
+        self._give(self._key("grad", net, save.capacity, save.act.device, precision), ws)
+
+
+def _pool(owner) -> WorkspacePool:
+    if getattr(owner, "ws_pool", None) is None:
+        owner.ws_pool = WorkspacePool()
+    return owner.ws_pool
+
+
 def _cap_needed(st: RenderSettings) -> bool:
     """The cap of model/mc_nerf.py:630-632 can only bind when a ray can select more than 128 samples."""
     return st.samples_f > st.max_fine_per_ray
@@ -85,9 +129,9 @@ class RenderTrainFn(torch.autograd.Function):
         net_c = model_c.net
         flat_c = model_c.flat_params()
         prec = st.precision
-        packed_c = ops.pack_weights(net_c, flat_c, precision=prec)
+        packed_c = ops.pack_weights(net_c, flat_c, precision=prec, range_flags=model_c.range_flags(prec, dev))
         out_c = torch.empty(N, st.samples_c, 4, dtype=torch.float32, device=dev)
-        save_c = ops.alloc_save(net_c, N * st.samples_c, dev, precision=prec) if need_grad else None
+        save_c = _pool(owner).take_save(net_c, N * st.samples_c, dev, prec) if need_grad else None
         ops.mlp_fwd(net_c, flat_c, packed_c, rays_o, rays_d, owner.z_vals_c, jit, barf_w, out_c, save=save_c, precision=prec)
         rgb_c, depth_c, _, w_sel, wmax = ops.composite_fwd(out_c, rays_d, owner.z_vals_c, jit, eps_c,
                                                           None if only_coarse else eps_sel, st.white_back,
@@ -106,8 +150,8 @@ class RenderTrainFn(torch.autograd.Function):
         idx, count, out_f, max_rows = select_and_cap(st, w_sel, wmax, N, cap_perm, train=True)
         net_f = model_f.net
         flat_f = model_f.flat_params()
-        packed_f = ops.pack_weights(net_f, flat_f, precision=prec)
-        save_f = ops.alloc_save(net_f, max_rows, dev, precision=prec) if need_grad else None
+        packed_f = ops.pack_weights(net_f, flat_f, precision=prec, range_flags=model_f.range_flags(prec, dev))
+        save_f = _pool(owner).take_save(net_f, max_rows, dev, prec) if need_grad else None
         ops.mlp_fwd(net_f, flat_f, packed_f, rays_o, rays_d, owner.z_vals_f, jit, barf_w, out_f,
                     idx=idx, count=count, max_rows=max_rows, save=save_f, precision=prec)
         rgb_f, _, _, _, _ = ops.composite_fwd(out_f, rays_d, owner.z_vals_f, jit, eps_f, None, st.white_back)
@@ -145,11 +189,14 @@ class RenderTrainFn(torch.autograd.Function):
                 return
             net = model.net
             d_out, gmax = ops.composite_bwd(out, zgrid, jit, eps, d_rgb.contiguous(), st.white_back, want_gmax=True)
-            dy, dsh = ops.alloc_grad_ws(net, save, st.precision)
+            pool = _pool(owner)
+            dy, dsh = pool.take_grad(net, save, st.precision)
             ops.mlp_bwd(net, flat, packed, rays_o, rays_d, zgrid, jit, barf_w, out, d_out, save, dy, dsh,
                         d_o, d_d, idx=idx, count=count, max_rows=max_rows, precision=st.precision, gmax=gmax)
             rows = max_rows if idx is not None else N * zgrid.numel()
             ops.mlp_dw(net, save, dy, dsh, grads, rows, count=count, precision=st.precision, gmax=gmax)
+            pool.give_grad(net, save, st.precision, (dy, dsh))
+            pool.give_save(net, save, st.precision)           # (everything that reads the set is enqueued: the next step may overwrite it)
 
         if not ctx.only_coarse:
             eps_f, out_f, flat_f, packed_f, idx, count = saved[8:]
@@ -178,7 +225,8 @@ def render_test(owner, model_c, model_f, rays_d, rays_o, eps_c, eps_sel, eps_f, 
     flat_c, flat_f = model_c.flat_params(), model_f.flat_params()
     prec = st.precision
     if prepared is None:
-        prepared = (ops.pack_weights(net_c, flat_c, precision=prec), ops.pack_weights(net_f, flat_f, precision=prec),
+        prepared = (ops.pack_weights(net_c, flat_c, precision=prec, range_flags=model_c.range_flags(prec, dev)),
+                    ops.pack_weights(net_f, flat_f, precision=prec, range_flags=model_f.range_flags(prec, dev)),
                     owner.emmbedding_xyz.barf_weights_on(1, dev))
     packed_c, packed_f, barf_w = prepared
     out_c = torch.empty(N, st.samples_c, 4, dtype=torch.float32, device=dev)

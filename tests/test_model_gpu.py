@@ -514,6 +514,14 @@ def test_rig_configs_one_global_optim_step(gpu_device, rig, H, samples, scale, p
     # gradients, relative to the subset's largest: f16x3 within 8x of the reference's own reorder noise (measured 1-4x; floor 1e-3:
     # 128 rays sample the noise thinly), bf16 its 8-bit operands (measured 3e-2 .. 6e-2)
     tol_g = {"f16x3": 8.0 * max(noise, 1e-3), "bf16": 0.15}[precision]
+    ec = float((rgb_c[sub] - r["rgb_c"].detach()).abs().max())
+    ef = float((rgb_f[sub] - r["rgb_f"].detach()).abs().max())
+    gd_, go_ = seen["d"].grad.cpu()[sub], seen["o"].grad.cpu()[sub]
+    eg_d = float((gd_ - d_leaf.grad).abs().max() / d_leaf.grad.abs().max())
+    eg_o = float((go_ - o_leaf.grad).abs().max() / o_leaf.grad.abs().max())
+    msg = (f"[{rig} {H}x{W} {samples}x{scale} {precision}] C = {C}, {k} fine samples ({'cap binds' if capped else 'no cap'}), subset of {n_sub} "
+           f"({idx_sub.shape[0]} kept): max|rgb_c - oracle| {ec:.1e}, max|rgb_f - oracle| {ef:.1e}, d_rays_d {eg_d:.1e}, d_rays_o {eg_o:.1e} "
+           f"(relative to the largest; the oracle's own reorder noise {noise:.1e})")
     print(msg)
     assert ec < tol and ef < tol, msg
     assert eg_d < tol_g and eg_o < tol_g, msg
@@ -1093,3 +1101,39 @@ def test_standalone_module_forwards_match_reference_modules(gpu_device):
         (eg * we.to(dev)).sum().backward()
         assert float((xg.grad.cpu() - xr.grad).abs().max()) < 1e-4 * max(1.0, float(xr.grad.abs().max()))
     assert not emb(x.to(dev), 0.5).requires_grad                   # nothing requires a gradient: plain inference call
+
+
+@pytest.mark.parametrize("precision,value", [("f16x3", 300.0), ("f16", 7.0e4)])
+def test_refused_step_names_the_weight_tensor_out_of_range(gpu_device, precision, value):
+    """The operand ranges of the reduced-precision modes are a contract (f16x3: |w| <= 255.9, f16: 65504; csrc/mcnerf_x3.h): a
+    weight beyond it becomes inf in the packed stream, the gradients NaN, and the fused RAdam refuses the step.  The packing
+    kernel flags the offending TENSOR and RAdam.raise_on_overflow() names it -- "skipped step" is an actionable error."""
+    from mc_nerf_amd import _lib, ops, synthetic as S
+    from mc_nerf_amd.model import MC_NeRF_Loss, NeRF_Model, RAdam
+    dev = gpu_device
+    sp = S.make_sys_param(dev, samples=32, scale=2, batch=128, H=32, W=32, coarse=(4, 32, [2]), fine=(8, 64, [4]), precision=precision)
+    torch.manual_seed(3)
+    m = NeRF_Model(sp).to(dev)
+    opt = RAdam(m.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(1)
+    o = torch.nn.functional.normalize(torch.randn(128, 3, generator=g), dim=-1).to(dev) * 3.0
+    d = torch.nn.functional.normalize(-o.cpu() + 0.3 * torch.randn(128, 3, generator=g), dim=-1).to(dev)
+    gt = torch.rand(128, 3, generator=g).to(dev)
+
+    def step():
+        rgb_c, rgb_f = m.render_rays_train(d, o, 0, 1.0)
+        loss = MC_NeRF_Loss(sp).get_rgb_loss([rgb_c, rgb_f, gt])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    step()
+    assert opt.skipped_steps() == 0 and ops.range_report() == []
+    opt.raise_on_overflow()                                   # nothing to report
+    with torch.no_grad():
+        m.nerf_fine.xyz_encoding_3[0].weight[5, 7] = value
+    before = m.nerf_fine.sigma[0].weight.detach().clone()
+    step()
+    assert opt.skipped_steps() == 1 and torch.equal(before, m.nerf_fine.sigma[0].weight.detach())
+    assert ("fine net", "xyz_encoding_3.0.weight", precision) in ops.range_report()
+    with pytest.raises(_lib.McnerfError, match=r"fine net xyz_encoding_3\.0\.weight"):
+        opt.raise_on_overflow()
