@@ -496,7 +496,7 @@ def run_rank(args):
         if world > 1:
             dist.destroy_process_group()
         return
-    head, k_mean = run_precision(args.precision, args, args.steps, args.warmup, rank, world, dev, timer, cache)
+    head, k_mean = run_precision(args.precision, args, args.steps, args.warmup, rank, world, dev, timer, cache, occupancy=args.rho)
     others = {}
     for p in [q for q in args.also.split(",") if q and q != args.precision]:
         others[p], _ = run_precision(p, args, max(20, args.steps // 5), 3, rank, world, dev, timer, cache)
@@ -505,7 +505,7 @@ def run_rank(args):
     # coarse net shifted; K reported with each), in the headline mode and in f16; and the "coarse also 8x256/[4]" variant
     by_occ, extra = {}, {}
     sub_steps = max(20, args.steps // 2)
-    default_shape = (args.rays == 32768 and args.samples == 64 and args.scale == 2 and args.img == 800 and args.coarse == "4x128x2")
+    default_shape = (args.rays == 32768 and args.samples == 64 and args.scale == 2 and args.img == 800 and args.coarse == "4x128x2" and args.rho is None)
     if args.occupancy:
         for rho in [float(t) for t in args.occupancy.split(",") if t]:
             by_occ[f"{rho:g}"] = {p: slim(run_precision(p, args, sub_steps, 3, rank, world, dev, timer, cache, occupancy=rho)[0])
@@ -553,6 +553,7 @@ def run_rank(args):
             "dtype": DTYPE_TEXT[args.precision], "data": "synthetic",
             "config": {"workload": workload_text(args), "precision": args.precision, "rays_per_step_per_gpu": args.rays,
                        "fine_samples_per_ray": head["fine_samples_per_ray"], "selected_fraction": head["selected_fraction"],
+                       "occupancy": head.get("occupancy"),
                        "parallelism": f"dp{world} (cameras sharded, 1 flat all-reduce/step)"},
             "roofline": roof,
             "kernel_ms": head["kernel_ms"],
@@ -639,6 +640,8 @@ def main():
     ap.add_argument("--coarse", default="4x128x2", help="coarse net depth x width x skip (config/config.yaml:76-78); 8x256x4 = SURVEY 8's second variant")
     ap.add_argument("--occupancy", default="0.25,0.05", help="selected fractions of the fine grid measured beside the random-init line "
                     "(by_occupancy; sigma-head bias shift, SURVEY 8(d)); empty = none")
+    ap.add_argument("--rho", type=float, default=None, help="pin the selected fraction of the HEADLINE run itself (profiling a low-occupancy step: "
+                    "scripts/evidence.sh); the default line leaves the random-init weights as they are")
     ap.add_argument("--no-extra", dest="extra", action="store_false", help="skip extra_lines (8x256 coarse, N = 7000, 128x5, render)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16", "bf16"],

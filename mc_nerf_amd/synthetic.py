@@ -96,7 +96,7 @@ def array_cameras(seed: int = 0, H: int = 800, W: int = 800):
         r = np.linalg.norm(loc[:2])
         phi = math.atan(loc[2] / r)
         v = loc[:2] / r
-        cos_t, sin_t = float(np.dot(v, [0.0, -1.0])), float(np.cross(v, [0.0, -1.0]))
+        cos_t, sin_t = float(np.dot(v, [0.0, -1.0])), float(v[0] * -1.0 - v[1] * 0.0)        # (2-D cross product v x (0, -1))
         theta = 2 * math.pi - math.acos(max(-1.0, min(1.0, cos_t))) if sin_t > 0 else math.acos(max(-1.0, min(1.0, cos_t)))
         eulers.append((math.radians(90) - phi, theta))
     return _rig_tensors(cord, eulers, fovs, H, W)

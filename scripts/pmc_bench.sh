@@ -4,7 +4,7 @@
 TAG=$1; PREC=$2
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-CMD="python3 bench.py --steps 4 --warmup 2 --also= --no-cpu-baseline --precision $PREC"
+CMD="python3 bench.py --steps 4 --warmup 2 --also= --occupancy= --no-extra --no-cpu-baseline --precision $PREC"
 for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p gpurun_out/pmc_${TAG}_${PREC}_$c
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_${PREC}_$c -- $CMD > gpurun_out/pmc_${TAG}_${PREC}_$c/log.txt 2>&1
