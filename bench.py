@@ -307,7 +307,11 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
     cams = D.shard_cameras(C, 0, rank, world, seed=42)
     counts, ar_events = [], []
     occ = None
-    if occupancy is not None:
+    if occupancy is not None and args.sigma_bias_shift is not None:      # (a shift calibrated by an earlier run: no calibration renders in a profiled run)
+        with torch.no_grad():
+            model.nerf.nerf_coarse.sigma[2].bias.add_(args.sigma_bias_shift)
+        occ = {"target": occupancy, "sigma_bias_shift": args.sigma_bias_shift, "selected_fraction_at_calibration": None}
+    elif occupancy is not None:
         def nograd_step(i):
             model((images, torch.tensor([cams[i % len(cams)]]), wpts, pts, wpts, pts), 20, "GLOBAL_OPTIM_EPOCH", 0.6)
         shift, got = calibrate_occupancy(model, nograd_step, occupancy, rays * samples * scale)
@@ -642,6 +646,8 @@ def main():
                     "(by_occupancy; sigma-head bias shift, SURVEY 8(d)); empty = none")
     ap.add_argument("--rho", type=float, default=None, help="pin the selected fraction of the HEADLINE run itself (profiling a low-occupancy step: "
                     "scripts/evidence.sh); the default line leaves the random-init weights as they are")
+    ap.add_argument("--sigma-bias-shift", type=float, default=None, help="with --rho: apply this shift (from an earlier run's "
+                    "`occupancy.sigma_bias_shift`) instead of calibrating")
     ap.add_argument("--no-extra", dest="extra", action="store_false", help="skip extra_lines (8x256 coarse, N = 7000, 128x5, render)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16", "bf16"],

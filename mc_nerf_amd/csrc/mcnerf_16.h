@@ -138,6 +138,8 @@ struct Mcn16DwArgs {
     size_t slot_bytes;
     float* grads;
     const unsigned* gmax_bits;
+    // (f16x3: the sigma hidden layer's dY is synthesised from these, mlp_x3_dw.hip)
+    const float* params; const unsigned* mask_ws; size_t mask_slot_words;
 };
 hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st);
 hipError_t mcn16_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, int bf16, unsigned* range_flags, hipStream_t st);
@@ -276,6 +278,13 @@ __device__ __forceinline__ void mcn16_dma16_nt(const char* gsrc, unsigned lds_ds
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// ... SADDR form: wave-uniform base (a scalar register pair) + the lane's 32-bit byte offset.  A stream whose pieces differ only in
+// a uniform base keeps ONE vector register of addressing state instead of a 64-bit pointer per piece.
+__device__ __forceinline__ void mcn16_dma16_nt_s(const char* ubase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(ubase), "s"(lds_dst) : "memory");
 }
 // 256-byte piece: one dword per lane (LDS destination = lds_dst + lane * 4)
 __device__ __forceinline__ void mcn16_dma4(const void* gsrc, unsigned lds_dst) {

@@ -13,8 +13,9 @@ for P in f16x3 f16; do
   scripts/pmc_bench.sh $TAG $P > gpurun_out/${TAG}_pmc_table_$P.txt 2>&1
 done
 # the step at a pinned selected fraction of 0.05 (SURVEY 8(d)'s low-occupancy regime): per-kernel table
+SHIFT=$(python3 -c "import json; print(json.load(open('gpurun_out/${TAG}_bench_default.json'))['by_occupancy']['0.05']['f16x3']['occupancy']['sigma_bias_shift'])")
 for P in f16x3 f16; do
-  scripts/prof_bench.sh ${TAG}_rho005_$P --steps 10 --warmup 3 --rho 0.05 --also= --occupancy= --no-extra --no-cpu-baseline --precision $P > gpurun_out/${TAG}_kernel_table_rho005_$P.txt 2>&1
+  scripts/prof_bench.sh ${TAG}_rho005_$P --steps 10 --warmup 3 --rho 0.05 --sigma-bias-shift $SHIFT --also= --occupancy= --no-extra --no-cpu-baseline --precision $P > gpurun_out/${TAG}_kernel_table_rho005_$P.txt 2>&1
   cp gpurun_out/prof_${TAG}_rho005_$P/kernel_stats.csv gpurun_out/${TAG}_kernel_stats_rho005_$P.csv
 done
 mkdir -p gpurun_out/sq_$TAG

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): scripts/prof_bench.sh <tag> [bench args...]
 # rocprofv3 --kernel-trace --stats of the bench command; prints the per-step kernel table (steps = timed + warm-up + the
-# KernelTimer's min(5, steps) untimed extra steps; a --rho run adds 45 forward-only calibration renders: no-save kernels)
+# KernelTimer's min(5, steps) untimed extra steps; profile a --rho run with --sigma-bias-shift, or its calibration renders are in the table)
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
