@@ -161,12 +161,9 @@ int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* pa
                       int n_rays, int S, const float* out, const float* d_out,
                       const uint32_t* mask_ws, long long capacity, const void* enc_ws, const void* sh_ws,
                       void* dy_ws, void* dsh_ws, float* d_rays_o, float* d_rays_d, const uint32_t* gmax_bits, void* stream);
-/* mcnerf_mlp_dw in these modes (fp32 accumulation and fp32 float-atomic output into `grads`).  `params` and `mask_ws` (the
- * forward's ReLU bit words): in dtype 2 the backward does not write the sigma hidden layer's pre-activation gradient (a rank-1
- * function of its ReLU bits, d sigma and the sigma.2 row); this kernel synthesises it per tile from those instead of reading
- * 1 KiB per row back -- the slot of dy_ws is unused in that mode. */
-int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const float* params, const int32_t* count, int rows,
-                     const void* act_ws, const void* enc_ws, const uint32_t* mask_ws, const void* dy_ws, const void* dsh_ws,
+/* mcnerf_mlp_dw in these modes (fp32 accumulation and fp32 float-atomic output into `grads`). */
+int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const int32_t* count, int rows,
+                     const void* act_ws, const void* enc_ws, const void* dy_ws, const void* dsh_ws,
                      long long capacity, float* grads, const uint32_t* gmax_bits, void* stream);
 
 /* Alpha compositing of [N,S] samples per ray.

@@ -52,7 +52,7 @@ SIGNATURES = {
     "mcnerf_mlp_fwd_16": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
     "mcnerf_mlp_bwd_16": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _P,
                                _P, _P, _P, _P, _P, _P]),
-    "mcnerf_mlp_dw_16": (_I, [_I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
+    "mcnerf_mlp_dw_16": (_I, [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P]),
     "mcnerf_composite_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mcnerf_composite_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "mcnerf_select_fine": (_I, [_P, _P, c_float, _I, _I, _I, c_float, _P, _P, _P, _P, _P, _P]),

@@ -273,16 +273,15 @@ int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* pa
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d; a.gmax_bits = gmax_bits;
     return check("mcnerf_mlp_bwd_16", dtype == 2 ? mcnx3_launch_bwd(a, (hipStream_t)stream) : mcn16_launch_bwd(a, (hipStream_t)stream));
 }
-int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const float* params, const int32_t* count, int rows,
-                     const void* act_ws, const void* enc_ws, const uint32_t* mask_ws, const void* dy_ws, const void* dsh_ws,
+int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const int32_t* count, int rows,
+                     const void* act_ws, const void* enc_ws, const void* dy_ws, const void* dsh_ws,
                      long long capacity, float* grads, const uint32_t* gmax_bits, void* stream) {
     REQ(net_ok(depth, width, skip) && dtype_ok(dtype), "mcnerf_mlp_dw_16");
-    REQ(params && act_ws && enc_ws && mask_ws && dy_ws && dsh_ws && grads && gmax_bits && rows >= 0 && capacity >= rows, "mcnerf_mlp_dw_16");
+    REQ(act_ws && enc_ws && dy_ws && dsh_ws && grads && gmax_bits && rows >= 0 && capacity >= rows, "mcnerf_mlp_dw_16");
     Mcn16DwArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
     a.bf16 = dtype; a.count = count; a.rows = rows; a.act_ws = act_ws; a.enc_ws = enc_ws; a.dy_ws = dy_ws; a.dsh_ws = dsh_ws;
     a.slot_bytes = slot_bytes_of(dtype, capacity, width); a.grads = grads; a.gmax_bits = gmax_bits;
-    a.params = params; a.mask_ws = mask_ws; a.mask_slot_words = mcn16_mask_slot_bytes(capacity, width) / 4;
     return check("mcnerf_mlp_dw_16", dtype == 2 ? mcnx3_launch_dw(a, (hipStream_t)stream) : mcn16_launch_dw(a, (hipStream_t)stream));
 }
 

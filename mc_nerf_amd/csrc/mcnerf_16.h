@@ -138,8 +138,6 @@ struct Mcn16DwArgs {
     size_t slot_bytes;
     float* grads;
     const unsigned* gmax_bits;
-    // (f16x3: the sigma hidden layer's dY is synthesised from these, mlp_x3_dw.hip)
-    const float* params; const unsigned* mask_ws; size_t mask_slot_words;
 };
 hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st);
 hipError_t mcn16_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, int bf16, unsigned* range_flags, hipStream_t st);

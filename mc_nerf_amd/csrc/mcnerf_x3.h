@@ -18,9 +18,6 @@
 #pragma once
 #include "mcnerf_16.h"
 
-#ifndef MCNX3_SYNTH_SIGMA0
-#define MCNX3_SYNTH_SIGMA0 1           // the sigma hidden layer's dY planes: 1 = synthesised in mlp_x3_dw.hip, not stored by mlp_x3_bwd.hip; 0 = stored and read back
-#endif
 #define MCNX3_SW 256.0f
 #define MCNX3_SX 8.0f
 #define MCNX3_SLABF 8                  // logical fragments (hi + lo piece) per ring slab

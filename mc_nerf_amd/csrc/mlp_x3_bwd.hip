@@ -6,9 +6,8 @@
 //   sigmoid / SH backward (lane-local) -> sigma.0^T (kept as a (hi, lo) partial) -> sh.2^T -> sh.0^T (+ partial) ->
 //   trunk D-1 .. 1 (the skip layer's and layer 0's encoded columns accumulate the encoded-input gradient in fp32) ->
 //   encoding backward -> per-ray d o / d d (segmented wave reduction + fp32 atomics).
-// Every pre-activation gradient but the sigma hidden layer's (an outer product the weight-gradient kernel rebuilds from the ReLU
-// bits and d sigma) is written fragment-major, hi plane then lo plane, to dy_ws / dsh_ws (operands of mlp_x3_dw.hip), scaled by
-// the per-launch power of two SG (f16 range; derived from max|d_out|).
+// Every pre-activation gradient is written fragment-major, hi plane then lo plane, to dy_ws / dsh_ws (operands of
+// mlp_x3_dw.hip), scaled by the per-launch power of two SG (f16 range; derived from max|d_out|).
 // Replaces autograd through model/net_block.py:22-33, 67-78 and model/mc_nerf.py:602, 635, 690-691.
 #include "mcnerf_x3.h"
 #include <cstdlib>
@@ -363,12 +362,8 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
                 xah[s][d] = mcn16_pkmul(wh, bits);
                 xal[s][d] = mcn16_pkmul(wl, bits);
             }
-            // (not stored: the weight-gradient kernel synthesises this slot's planes from the ReLU bits, d sigma -- column 27 of the dsh
-            //  planes written above -- and the sigma.2 row: mlp_x3_dw.hip, SYNTH; 1 KiB per row less to write and to read back at width 256)
-#if !MCNX3_SYNTH_SIGMA0
             mcn16_ws_store(xah[s], reinterpret_cast<u32x4_t*>(dy_lane + (size_t)D * a.slot_bytes + s * 1024));
             mcn16_ws_store(xal[s], reinterpret_cast<u32x4_t*>(dy_lane + (size_t)D * a.slot_bytes + (KS + s) * 1024));
-#endif
         }
         // ---- sigma.0^T (partial, (hi, lo)) ; sh.2^T -> dY of sh.0 ; sh.0^T + partial -> dY_{D-1}
         if (D >= 2) mask_issue(mask_lane, D - 2, buf_of(D - 2));          // buffer 0 is free (the sigma path is done)

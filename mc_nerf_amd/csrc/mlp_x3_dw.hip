@@ -21,12 +21,6 @@ struct DwX3Seg {
     int col2, k_real2;            // input K + k of X2: column col2 + k, real for k < k_real2
     float* dW; int ldw;
     float* db;
-    // shape 4 (the sigma head's hidden layer): dY is not read but SYNTHESISED per tile from what it is a function of --
-    // dY[m][n] = relu_bit[m][n] * w2[n] * d sigma[m] (mlp_x3_bwd.hip "dY of sigma.0") -- i.e. from the forward's ReLU bits of that
-    // slot (1 KiB per tile), the d sigma column of the dsh planes (2 x 1 KiB per tile) and the sigma.2 weight row
-    const unsigned* mask;         // ReLU bit words of the slot: [tile][64 lanes][mask_words]
-    const char* dsh;              // fragment-major d(sh.2 outputs | sigma) planes: [tile][hi k0, hi k1, lo k0, lo k1][64][8]
-    const float* w2;              // sigma.2 weight row [N]
 };
 
 constexpr int dwx3_pick(int N, int K, bool want_vn) {
@@ -59,19 +53,6 @@ __device__ __forceinline__ void dwx3_wait(bool full_x, bool full_y, bool steady)
 #undef DWX3_W
 }
 
-// ... for the synthesised-dY segments: NX X quarters and NR raw-input pieces may still be in flight (cx in {PWX, PWX - 1}, this
-// wave's raw piece count 1 or 0)
-template <int NX, int NR, int PWX>
-__device__ __forceinline__ void dwx3_wait_syn(bool full_x, bool has_raw, bool steady) {
-#define DWX3_W(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
-    if (!steady) DWX3_W(0);
-    else if (full_x && has_raw) DWX3_W(NX * PWX + NR);
-    else if (full_x) DWX3_W(NX * PWX);
-    else if (has_raw) DWX3_W(NX * (PWX > 0 ? PWX - 1 : 0) + NR);
-    else DWX3_W(NX * (PWX > 0 ? PWX - 1 : 0));
-#undef DWX3_W
-}
-
 // tiles [t0, t1) of one segment: stream, accumulate, flush.
 // A tile's four operand planes are QUARTERS of a tile slot, issued, consumed and freed in the order
 //     X_lo, dY_hi, X_hi, dY_lo:   step A  acc += dY_hi X_lo  (frees X_lo)
@@ -81,17 +62,7 @@ __device__ __forceinline__ void dwx3_wait_syn(bool full_x, bool has_raw, bool st
 // R = 2 slots that a 256 x 256 block leaves room for, 80-96 KiB are in flight per CU at any time instead of one whole tile
 // (64 KiB) issued once per tile.  One counted vmcnt wait + raw barrier per step; leaves no LDS-DMA piece outstanding and every
 // wave past the barrier that follows the last LDS read.
-//
-// SYNTH (shape 4): the dY planes of a tile are written into the slot's dY quarters by the workgroup itself instead of arriving by
-// DMA: 2 KiB per sample-row less to write in the backward chain and 2 KiB less to read here at width 256 (1 KiB at 128).  The
-// raw inputs of tile j -- 3 pieces of <= 1 KiB: the ReLU-bit tile and the hi / lo fragment holding the d sigma column -- travel
-// through a ring of R + 2 entries behind the tile slots, issued R + 1 tiles ahead (one piece per wave 0 .. 2 (3), at step C),
-// and tile j + 1 is synthesised during step A of tile j, after the barrier that shows every wave past step C of tile j - 1
-// (the slot's last reader).  The counted waits of steps A and B then read (2R - 2) c_X + (R - 1) c_raw (derivation beside
-// dwx3_wait_syn's call sites); step C needs neither a wait nor a barrier (nothing lands for it, nothing it frees is refilled
-// by DMA).  The values are the backward chain's own arithmetic (same products, same hi / lo split, same masking) on d sigma as
-// the weight-gradient kernels have always read it: the (hi, lo) pair of the dsh plane, 22 bits.
-template <int N, int K1, int K2, int SYNTH = 0>
+template <int N, int K1, int K2>
 __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const int t1, const float sgs, char* smem) {
     constexpr int K = K1 + K2;
     constexpr int KSN = N / 16, KSK1 = K1 / 16, KSK2 = K2 / 16, KSK = KSK1 + KSK2, P2 = 2 * (KSN + KSK);   // 1 KiB pieces per tile
@@ -112,53 +83,12 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
     const unsigned lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)smem);
     const int hh = lane >> 5, mm = lane & 31;
     const int nx = (KSK > wave) ? (KSK - wave + MCN16_WAVES - 1) / MCN16_WAVES : 0;        // wave-uniform piece counts
-    const int ny = SYNTH ? 0 : ((KSN > wave) ? (KSN - wave + MCN16_WAVES - 1) / MCN16_WAVES : 0);
-    // ---- SYNTH: the raw-input ring (entry = 3 KiB: ReLU-bit tile | d sigma fragment hi | lo) and this wave's piece of it
-    constexpr int MWD = N >= 64 ? N / 64 : 1;                             // mask dwords per lane
-    constexpr int RQ = R + 2, oRaw = R * SLOT, oW2 = oRaw + RQ * 3072;       // (oW2: the sigma.2 row [N] fp32, staged once per run)
-    const bool has_raw = SYNTH && (wave < 3 || (MWD == 2 && wave == 3));
-    auto issue_raw = [&](int j) {                                         // (j = tile index relative to t0)
-        if (!has_raw) return;
-        const unsigned dst = lds_base + oRaw + (j % RQ) * 3072;
-        const size_t tile = (size_t)(t0 + j);
-        if (wave == 1) mcn16_dma16_nt(sg.dsh + tile * 4096 + 1024 + lane * 16, dst + 1024);
-        else if (wave == 2) mcn16_dma16_nt(sg.dsh + tile * 4096 + 3072 + lane * 16, dst + 2048);
-        else if (MWD == 4) mcn16_dma16_nt(reinterpret_cast<const char*>(sg.mask + (tile * 64 + lane) * 4), dst);
-        else mcn16_dma4(sg.mask + (tile * 64 + lane) * MWD + (wave == 3 ? 1 : 0), dst + (wave == 3 ? 256 : 0));
-    };
-    // tile j's dY planes -> the dY quarters of `slot` (every thread: chunks tid, tid + 512, ... of KSN x 64 per plane)
-    auto synth = [&](int j, int slot) {
-        const char* raw = smem + oRaw + (j % RQ) * 3072;
-        for (int q = tid; q < KSN * 64; q += 64 * MCN16_WAVES) {
-            const int s_ = q >> 6, l = q & 63, h_ = l >> 5, m_ = l & 31, t_ = s_ >> 1, u_ = s_ & 1;
-            const unsigned mk = MWD == 4 ? *reinterpret_cast<const unsigned*>(raw + l * 16 + (t_ >> 1) * 4)
-                                         : *reinterpret_cast<const unsigned*>(raw + (t_ >> 1) * 256 + l * 4);
-            const float dsig = (float)*reinterpret_cast<const _Float16*>(raw + 1024 + m_ * 16 + 14) +
-                               (float)*reinterpret_cast<const _Float16*>(raw + 2048 + m_ * 16 + 14);     // column 27 = (k-step 1, h 0, element 7)
-            // (from LDS: a global load in this loop would make hipcc drain vmcnt -- the X quarters in flight -- once per tile: measured 2.2 x)
-            const float* w2s = reinterpret_cast<const float*>(smem + oW2);
-            const f32x4 wa = *reinterpret_cast<const f32x4*>(w2s + 16 * s_ + 4 * h_), wb = *reinterpret_cast<const f32x4*>(w2s + 16 * s_ + 8 + 4 * h_);
-            u32x4_t vh, vl;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const float va = (d < 2 ? wa[2 * d] : wb[2 * d - 4]) * dsig, vb = (d < 2 ? wa[2 * d + 1] : wb[2 * d - 3]) * dsig;
-                const unsigned bits = (mk >> (8 * (t_ & 1) + 7 - (4 * u_ + d))) & 0x00010001u;
-                unsigned wh, wl;
-                mcnx3_split2(va, vb, wh, wl);
-                vh[d] = mcn16_pkmul(wh, bits);
-                vl[d] = mcn16_pkmul(wl, bits);
-            }
-            const int off = s_ * 1024 + (32 * h_ + (m_ ^ (4 * (2 * u_ + h_)))) * 16;
-            *reinterpret_cast<u32x4_t*>(smem + slot * SLOT + oYhi + off) = vh;
-            *reinterpret_cast<u32x4_t*>(smem + slot * SLOT + oYlo + off) = vl;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // (the LDS writes are complete before this wave reaches the next barrier)
-    };
+    const int ny = (KSN > wave) ? (KSN - wave + MCN16_WAVES - 1) / MCN16_WAVES : 0;
     const bool full_x = nx == PWX, full_y = ny == PWY;
     // Source addressing: piece i of a quarter is fragment s = wave + 8 i, so (s & 1) = (wave & 1) for every piece of this wave and the
     // lane's byte offset inside a fragment, (32 hh + (mm ^ 4 (2 (s & 1) + hh))) * 16, is ONE value for all X and dY pieces; what
     // differs per piece is a wave-uniform base (scalar registers).  (A 64-bit lane pointer per piece was 16 vector registers of
-    // this kernel's 256.)
+    // this kernel's 256: 29 -> 17 spilled, none of either inside a tile loop.)
     const unsigned voff = (unsigned)(hh * 32 + (mm ^ (4 * (2 * (wave & 1) + hh)))) * 16;
     const char* sxl[PWX > 0 ? PWX : 1]; const char* sxh[PWX > 0 ? PWX : 1];
     const char* syl[PWY > 0 ? PWY : 1]; const char* syh[PWY > 0 ? PWY : 1];
@@ -176,8 +106,8 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
 #pragma unroll
     for (int i = 0; i < PWY; ++i) {
         const int s = wave + MCN16_WAVES * i;
-        const char* p0 = SYNTH ? nullptr : sg.dY + ((size_t)t0 * 2 * KSN + s) * 1024;
-        syh[i] = p0; syl[i] = SYNTH ? nullptr : p0 + (size_t)KSN * 1024;
+        const char* p0 = sg.dY + ((size_t)t0 * 2 * KSN + s) * 1024;
+        syh[i] = p0; syl[i] = p0 + (size_t)KSN * 1024;
     }
     // quarter q of the NEXT tile to issue for it (each quarter keeps its own tile cursor through its source pointers)
     auto issue_x = [&](const char* (&src)[PWX > 0 ? PWX : 1], int slot, int off) {
@@ -188,7 +118,6 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
         }
     };
     auto issue_y = [&](const char* (&src)[PWY > 0 ? PWY : 1], int slot, int off) {
-        if (SYNTH) return;
 #pragma unroll
         for (int i = 0; i < PWY; ++i) {
             if (i < ny) mcn16_dma16_nt_s(src[i], voff, lds_base + slot * SLOT + off + (wave + MCN16_WAVES * i) * 1024);
@@ -231,21 +160,9 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
     };
 
     const int nt = t1 - t0;
-    if (SYNTH) {          // raw inputs of tiles 0 .. R, landed; tile 0 synthesised; then the X quarters of the first R tiles
 #pragma unroll
-        for (int i = 0; i <= R; ++i)
-            if (i < nt) issue_raw(i);
-        for (int i = tid; i < N; i += 64 * MCN16_WAVES) reinterpret_cast<float*>(smem + oW2)[i] = sg.w2[i];
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        synth(0, 0);
-#pragma unroll
-        for (int i = 0; i < R; ++i)
-            if (i < nt) { issue_x(sxl, i, oXlo); issue_x(sxh, i, oXhi); }
-    } else {
-#pragma unroll
-        for (int i = 0; i < R; ++i)
-            if (i < nt) { issue_x(sxl, i, oXlo); issue_y(syh, i, oYhi); issue_x(sxh, i, oXhi); issue_y(syl, i, oYlo); }
-    }
+    for (int i = 0; i < R; ++i)
+        if (i < nt) { issue_x(sxl, i, oXlo); issue_y(syh, i, oYhi); issue_x(sxh, i, oXhi); issue_y(syl, i, oYlo); }
     int slot = 0;
     for (int it = 0; it < nt; ++it) {
         const bool mine = (it % MS) == ms;                            // wave-uniform: waves sharing an output tile alternate tiles
@@ -253,14 +170,8 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
         const int pslot = (slot + R - 1) % R;                         // the previous tile's slot
         u32x4_t ah[2][VN], bx[2][KT];
         // ---- step A: dY_hi X_lo.  Landed: X_lo, dY_hi of this tile; every wave is past step C of the previous tile
-        // (SYNTH, steady state: per tile a wave issues X_hi at step A, X_lo at step B and its raw piece at step C.  Step A needs
-        //  X_lo(it), issued at B(it - R): younger are C(it - R)'s raw piece and R - 1 whole tiles = (2R - 2) c_X + R c_raw; and raw(it + 1),
-        //  issued at C(it - R): younger are R - 1 whole tiles = (2R - 2) c_X + (R - 1) c_raw -- the smaller count.  All of those exist
-        //  while it + R < nt.)
-        if (SYNTH) dwx3_wait_syn<2 * R - 2, R - 1, PWX>(full_x, has_raw, it >= R - 1 && it + R < nt);     // (the first R - 1 tiles: the raw pieces counted as younger were issued, and landed, before the X quarters)
-        else dwx3_wait<2 * R - 2, 2 * R - 2, PWX, PWY>(full_x, full_y, it + R - 1 < nt);
+        dwx3_wait<2 * R - 2, 2 * R - 2, PWX, PWY>(full_x, full_y, it + R - 1 < nt);
         if (it >= 1 && it - 1 + R < nt) { issue_x(sxh, pslot, oXhi); issue_y(syl, pslot, oYlo); }
-        if (SYNTH && it + 1 < nt) synth(it + 1, (slot + 1) % R);
         if (mine) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -279,10 +190,7 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
                 }
         }
         // ---- step B: dY_hi X_hi.  Landed: X_hi; every wave is past step A: X_lo of this slot is free
-        // (SYNTH: X_hi(it) was issued at A(it - R + 1): younger are B and C of that tile, R - 2 whole tiles and A(it)'s X_hi =
-        //  (2R - 2) c_X + (R - 1) c_raw)
-        if (SYNTH) dwx3_wait_syn<2 * R - 2, R - 1, PWX>(full_x, has_raw, it >= R - 1 && it + R < nt);
-        else dwx3_wait<2 * R - 2, 2 * R - 1, PWX, PWY>(full_x, full_y, it + R - 1 < nt);
+        dwx3_wait<2 * R - 2, 2 * R - 1, PWX, PWY>(full_x, full_y, it + R - 1 < nt);
         if (it + R < nt) issue_x(sxl, slot, oXlo);
         if (mine) {
 #pragma unroll
@@ -297,9 +205,8 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
                     for (int kt = 0; kt < KT; ++kt) acc[t][kt] = mcnx3_mfma(ah[u][t], bx[u][kt], acc[t][kt]);
         }
         // ---- step C: dY_lo X_hi.  Landed: dY_lo; every wave is past step B: dY_hi of this slot is free
-        if (!SYNTH) dwx3_wait<2 * R - 1, 2 * R - 2, PWX, PWY>(full_x, full_y, it + R < nt);
-        if (SYNTH) { if (it + R + 1 < nt) issue_raw(it + R + 1); }
-        else if (it + R < nt) issue_y(syh, slot, oYhi);
+        dwx3_wait<2 * R - 1, 2 * R - 2, PWX, PWY>(full_x, full_y, it + R < nt);
+        if (it + R < nt) issue_y(syh, slot, oYhi);
         if (mine) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -348,7 +255,7 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
 #define DWX3_MAXSEG 15
 struct DwX3Job {
     int n;
-    int shape[DWX3_MAXSEG];       // 0: W x W   1: W x 64 (encoded-input columns)   2: 32 x W (sh.2 / sigma.2 rows)   3: W x (W + 64) (skip layer)   4: W x W, dY synthesised (sigma.0)
+    int shape[DWX3_MAXSEG];       // 0: W x W   1: W x 64 (encoded-input columns)   2: 32 x W (sh.2 / sigma.2 rows)   3: W x (W + 64) (skip layer)
     DwX3Seg seg[DWX3_MAXSEG];
 };
 template <int W> struct DwX3SkipMerged { static constexpr bool value = (W == 256) || (W == 128); };
@@ -362,8 +269,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES) void dwx3_stream_kernel(DwX3Job j
     if (ntiles <= 0) return;
     const float gmax = gmax_bits ? __uint_as_float(*gmax_bits) : 1.f;
     const float sgs = mcn16_grad_scale(gmax);
-    // (work per 32-row tile of a shape in 2 KiB logical fragments read; shape 4 reads half of shape 0's but does all of its arithmetic)
-    auto pieces = [](int shape) { return shape == 0 ? 2 * W / 16 : shape == 1 ? W / 16 + MCN16_ENCKS : shape == 2 ? 2 + W / 16 : shape == 4 ? W / 16 + 2 : 2 * W / 16 + MCN16_ENCKS; };
+    auto pieces = [](int shape) { return shape == 0 ? 2 * W / 16 : shape == 1 ? W / 16 + MCN16_ENCKS : shape == 2 ? 2 + W / 16 : 2 * W / 16 + MCN16_ENCKS; };
     long long total = 0;
     for (int s = 0; s < job.n; ++s) total += (long long)pieces(job.shape[s]) * ntiles;
     const long long lo = total * blockIdx.x / gridDim.x, hi = total * (blockIdx.x + 1) / gridDim.x;
@@ -377,7 +283,6 @@ __global__ __launch_bounds__(64 * MCN16_WAVES) void dwx3_stream_kernel(DwX3Job j
         if (shape == 0) dwx3_run<W, W, 0>(job.seg[s], t0, t1, sgs, smem);
         else if (shape == 1) dwx3_run<W, 16 * MCN16_ENCKS, 0>(job.seg[s], t0, t1, sgs, smem);
         else if (shape == 2) dwx3_run<32, W, 0>(job.seg[s], t0, t1, sgs, smem);
-        else if (shape == 4) dwx3_run<W, W, 0, 1>(job.seg[s], t0, t1, sgs, smem);
         else if constexpr (SKIP_MERGED) dwx3_run<W, W, 16 * MCN16_ENCKS>(job.seg[s], t0, t1, sgs, smem);
     }
 }
@@ -405,7 +310,7 @@ static hipError_t dwx3_launch_job(const DwX3Job& job, const int* count, int rows
     // LDS: the largest stages x stage product over the shapes of this width
     constexpr int KS = W / 16;
     constexpr int p0 = 2 * (2 * KS), p1 = 2 * (KS + MCN16_ENCKS), p2 = 2 * (2 + KS), p3 = 2 * (2 * KS + MCN16_ENCKS);
-    constexpr int l0 = dwx3_slots(p0) * p0 + (dwx3_slots(p0) + 2) * 3 + 1, l1 = dwx3_slots(p1) * p1, l2 = dwx3_slots(p2) * p2, l3 = DwX3SkipMerged<W>::value ? dwx3_slots(p3) * p3 : 0;   // (l0: + shape 4's raw ring and sigma.2 row)
+    constexpr int l0 = dwx3_slots(p0) * p0, l1 = dwx3_slots(p1) * p1, l2 = dwx3_slots(p2) * p2, l3 = DwX3SkipMerged<W>::value ? dwx3_slots(p3) * p3 : 0;
     constexpr int lmax = (l0 > l1 ? l0 : l1) > (l2 > l3 ? l2 : l3) ? (l0 > l1 ? l0 : l1) : (l2 > l3 ? l2 : l3);
     static_assert(lmax <= 160, "ring exceeds the CU's LDS");
     const size_t lds = (size_t)lmax * 1024;
@@ -437,27 +342,20 @@ hipError_t mcnx3_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
         float* dWl = a.grads + L.pW[l];
         float* dbl = a.grads + L.pB[l];
         if (l == 0)                       // encoded-input columns only
-            add(1, DwX3Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl, nullptr, nullptr, nullptr});
+            add(1, DwX3Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl});
         else if (l == L.skip && merged)   // [hidden | encoded] in one pass: hidden k -> column 63 + k, encoded k -> column k
-            add(3, DwX3Seg{dy(l), KS, act(l - 1), KS, enc, MCN16_ENCKS, 0, W, MCN_ENC, W, 0, MCN_ENC, dWl, ldw, dbl, nullptr, nullptr, nullptr});
+            add(3, DwX3Seg{dy(l), KS, act(l - 1), KS, enc, MCN16_ENCKS, 0, W, MCN_ENC, W, 0, MCN_ENC, dWl, ldw, dbl});
         else if (l == L.skip) {
-            add(1, DwX3Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl, nullptr, nullptr, nullptr});
-            add(0, DwX3Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, MCN_ENC, W, 0, 0, dWl, ldw, nullptr, nullptr, nullptr, nullptr});
+            add(1, DwX3Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl});
+            add(0, DwX3Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, MCN_ENC, W, 0, 0, dWl, ldw, nullptr});
         } else
-            add(0, DwX3Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, dWl, ldw, dbl, nullptr, nullptr, nullptr});
+            add(0, DwX3Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, dWl, ldw, dbl});
     }
-    // sigma.0: its dY planes are not in dy_ws (mlp_x3_bwd.hip does not write them): synthesised from the ReLU bits of slot D, the
-    // d sigma column of dsh and the sigma.2 row (dwx3_run, SYNTH)
-#if MCNX3_SYNTH_SIGMA0
-    add(4, DwX3Seg{nullptr, KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWs1, W, a.grads + L.pBs1,
-                   a.mask_ws + (size_t)D * a.mask_slot_words, dsh, a.params + L.pWs2});
-#else
-    add(0, DwX3Seg{dy(D), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWs1, W, a.grads + L.pBs1, nullptr, nullptr, nullptr});
-#endif
-    add(0, DwX3Seg{dy(D + 1), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWc1, W, a.grads + L.pBc1, nullptr, nullptr, nullptr});
-    add(2, DwX3Seg{dsh, 2, act(D + 1), KS, nullptr, 0, 0, MCN_NSH, 0, W, 0, 0, a.grads + L.pWc2, W, a.grads + L.pBc2, nullptr, nullptr, nullptr});
+    add(0, DwX3Seg{dy(D), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWs1, W, a.grads + L.pBs1});
+    add(0, DwX3Seg{dy(D + 1), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWc1, W, a.grads + L.pBc1});
+    add(2, DwX3Seg{dsh, 2, act(D + 1), KS, nullptr, 0, 0, MCN_NSH, 0, W, 0, 0, a.grads + L.pWc2, W, a.grads + L.pBc2});
     // sigma.2 (1 x W): d sigma sits in column 27 of dsh, its input is the sigma hidden layer
-    add(2, DwX3Seg{dsh, 2, act(D), KS, nullptr, 0, MCN_NSH, MCN_NSH + 1, 0, W, 0, 0, a.grads + L.pWs2, W, a.grads + L.pBs2, nullptr, nullptr, nullptr});
+    add(2, DwX3Seg{dsh, 2, act(D), KS, nullptr, 0, MCN_NSH, MCN_NSH + 1, 0, W, 0, 0, a.grads + L.pWs2, W, a.grads + L.pBs2});
     switch (W) {
         case 256: return dwx3_launch_job<256>(job, a.count, a.rows, a.gmax_bits, st);
         case 128: return dwx3_launch_job<128>(job, a.count, a.rows, a.gmax_bits, st);

@@ -194,7 +194,7 @@ class RenderTrainFn(torch.autograd.Function):
             ops.mlp_bwd(net, flat, packed, rays_o, rays_d, zgrid, jit, barf_w, out, d_out, save, dy, dsh,
                         d_o, d_d, idx=idx, count=count, max_rows=max_rows, precision=st.precision, gmax=gmax)
             rows = max_rows if idx is not None else N * zgrid.numel()
-            ops.mlp_dw(net, save, dy, dsh, grads, rows, count=count, precision=st.precision, gmax=gmax, params=flat)
+            ops.mlp_dw(net, save, dy, dsh, grads, rows, count=count, precision=st.precision, gmax=gmax)
             pool.give_grad(net, save, st.precision, (dy, dsh))
             pool.give_save(net, save, st.precision)           # (everything that reads the set is enqueued: the next step may overwrite it)
 

@@ -324,14 +324,10 @@ def mlp_bwd(net: Net, params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Te
 
 
 def mlp_dw(net: Net, save: MlpSave, dy: Tensor, dsh: Tensor, grads: Tensor, rows: int,
-           count: Optional[Tensor] = None, precision: str = "f32", gmax: Optional[Tensor] = None, params: Optional[Tensor] = None) -> None:
-    """`params` (the flat parameter buffer): required in the register-chain modes (f16x3 synthesises the sigma hidden layer's
-    pre-activation gradient from the ReLU bits, d sigma and the sigma.2 row instead of reading it back: mlp_x3_dw.hip)."""
+           count: Optional[Tensor] = None, precision: str = "f32", gmax: Optional[Tensor] = None) -> None:
     if is16(precision):
-        if params is None:
-            raise _lib.McnerfError("mlp_dw in the register-chain modes needs the flat parameter buffer (`params`)")
-        _lib.call("mcnerf_mlp_dw_16", *net.triple, DTYPE16[precision], _p(params), _p(count, torch.int32), int(rows), _p(save.act, torch.uint8),
-                  _p(save.enc, torch.uint8), _p(save.mask, torch.int32), _p(dy, torch.uint8), _p(dsh, torch.uint8), save.capacity, _p(grads),
+        _lib.call("mcnerf_mlp_dw_16", *net.triple, DTYPE16[precision], _p(count, torch.int32), int(rows), _p(save.act, torch.uint8),
+                  _p(save.enc, torch.uint8), _p(dy, torch.uint8), _p(dsh, torch.uint8), save.capacity, _p(grads),
                   _p(gmax, torch.int32), _stream())
         return
     args = [*net.triple, _p(count, torch.int32), int(rows), _p(save.act), _p(save.enc), _p(dy), _p(dsh), save.capacity, _p(grads)]

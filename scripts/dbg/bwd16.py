@@ -43,7 +43,7 @@ for width in (32, 256):
     d_o = torch.zeros(N, 3, device=dev); d_d = torch.zeros(N, 3, device=dev)
     gmax = d_out.abs().max().reshape(1).view(torch.int32)
     ops.mlp_bwd(net, flat, packed, od, dd, zd, jd, bw, out, d_out, save, dy, dsh, d_o, d_d, idx=idx_d, count=count, max_rows=cap, precision=precision, gmax=gmax)
-    ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count, precision=precision, gmax=gmax, params=flat)
+    ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count, precision=precision, gmax=gmax)
     torch.cuda.synchronize()
     import math
     sg = 2.0 ** (4 - math.ceil(math.log2(float(d_out.abs().max()))))

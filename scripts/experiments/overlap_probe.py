@@ -32,7 +32,7 @@ d_o, d_d = torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev)
 ops.mlp_fwd(net, flat, packed, o, d, zg, None, bw, out, save=save, precision=prec)
 bwd = lambda: ops.mlp_bwd(net, flat, packed, o, d, zg, None, bw, out, d_out, save, dy, dsh, d_o, d_d, precision=prec, gmax=gmax)
 bwd2 = lambda: ops.mlp_bwd(net, flat, packed, o, d, zg, None, bw, out, d_out, save, dy2, dsh2, d_o, d_d, precision=prec, gmax=gmax)
-dw = lambda: ops.mlp_dw(net, save, dy2, dsh2, grads, N * S, precision=prec, gmax=gmax, params=flat)
+dw = lambda: ops.mlp_dw(net, save, dy2, dsh2, grads, N * S, precision=prec, gmax=gmax)
 bwd(); bwd2(); dw(); torch.cuda.synchronize()
 
 def timed(fn, reps=4):

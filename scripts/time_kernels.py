@@ -28,7 +28,7 @@ fns = {
     "fwd": lambda: ops.mlp_fwd(net, flat, packed, o, d, zg, None, bw, out, save=save, precision=prec),
     "fwd_nosave": lambda: ops.mlp_fwd(net, flat, packed, o, d, zg, None, bw, out, precision=prec),
     "bwd": lambda: ops.mlp_bwd(net, flat, packed, o, d, zg, None, bw, out, d_out, save, dy, dsh, d_o, d_d, precision=prec, gmax=gmax),
-    "dw": lambda: ops.mlp_dw(net, save, dy, dsh, grads, N * S, precision=prec, gmax=gmax, params=flat),
+    "dw": lambda: ops.mlp_dw(net, save, dy, dsh, grads, N * S, precision=prec, gmax=gmax),
 }
 # optional shader-clock probe (scripts/dbg/libclockprobe.so): a one-wave kernel on a side stream samples s_memtime against the
 # 100 MHz counter every 50 us while the timed kernel runs -> effective MHz under that kernel's load

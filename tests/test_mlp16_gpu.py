@@ -212,7 +212,7 @@ def test_mlp16_fwd_bwd_indexed(gpu_device, width, precision):
     gmax = d_out.abs().max().reshape(1).view(torch.int32)
     ops.mlp_bwd(net, flat, packed, od, dd, zd, jd, bw, out, d_out, save, dy, dsh, d_o, d_d,
                 idx=idx_d, count=count, max_rows=cap, precision=precision, gmax=gmax)
-    ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count, precision=precision, gmax=gmax, params=flat)
+    ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count, precision=precision, gmax=gmax)
     torch.cuda.synchronize()
 
     masks = ops.decode_masks_16(save.mask, nc.depth + 2, width, K)
@@ -270,7 +270,7 @@ def test_mlp16_dw_at_scale(gpu_device, width, precision):
     d_o, d_d = torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev)
     ops.mlp_bwd(net, flat, packed, od, dd, zd, None, bw, out, d_out, save, dy, dsh, d_o, d_d, precision=precision, gmax=gmax)
     grads = torch.zeros_like(flat)
-    ops.mlp_dw(net, save, dy, dsh, grads, rows, precision=precision, gmax=gmax, params=flat)
+    ops.mlp_dw(net, save, dy, dsh, grads, rows, precision=precision, gmax=gmax)
     torch.cuda.synchronize()
     sg = 2.0 ** (4 - math.ceil(math.log2(float(d_out.abs().max()))))
     act = ops.decode_frags_16(save.act, D + 2, W, rows, precision).double()

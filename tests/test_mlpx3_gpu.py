@@ -185,7 +185,7 @@ def test_x3_fwd_bwd_indexed(gpu_device, width):
     gmax = d_out.abs().max().reshape(1).view(torch.int32)        # what composite_bwd hands to the backward
     ops.mlp_bwd(net, flat, packed, od, dd, zd, jd, bw, out, d_out, save, dy, dsh, d_o, d_d,
                 idx=idx_d, count=count, max_rows=cap, precision=P, gmax=gmax)
-    ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count, precision=P, gmax=gmax, params=flat)
+    ops.mlp_dw(net, save, dy, dsh, grads, cap, count=count, precision=P, gmax=gmax)
     torch.cuda.synchronize()
     e_o, e_d = maxerr(d_o, o.grad), maxerr(d_d, d.grad)
     assert e_o < 2e-5 * max(1.0, float(o.grad.abs().max())), (e_o, float(o.grad.abs().max()))
@@ -228,7 +228,7 @@ def test_x3_dw_at_scale(gpu_device, width):
     d_o, d_d = torch.zeros(N, 3, device=dev), torch.zeros(N, 3, device=dev)
     ops.mlp_bwd(net, flat, packed, od, dd, zd, None, bw, out, d_out, save, dy, dsh, d_o, d_d, precision=P, gmax=gmax)
     grads = torch.zeros_like(flat)
-    ops.mlp_dw(net, save, dy, dsh, grads, rows, precision=P, gmax=gmax, params=flat)
+    ops.mlp_dw(net, save, dy, dsh, grads, rows, precision=P, gmax=gmax)
     torch.cuda.synchronize()
     sg = 2.0 ** (4 - math.ceil(math.log2(float(d_out.abs().max()))))
     sx = ops.SPLIT_SCALE_X
@@ -245,11 +245,7 @@ def test_x3_dw_at_scale(gpu_device, width):
         dyv = dyl(l)
         ref[f"xyz_encoding_{l + 1}.0.weight"] = gemm(dyv, x)
         ref[f"xyz_encoding_{l + 1}.0.bias"] = dyv.double().sum(0).cpu()
-    # sigma.0: its dY planes are not written by the backward (a rank-1 function of the ReLU bits of slot D, d sigma and the sigma.2
-    # row): the kernel synthesises them per tile -- the operand it uses, rebuilt here from the same three things
-    bits_s = ops.decode_masks_16(save.mask, D + 2, W, rows)[D].to(dev)
-    dy_sigma0 = bits_s.double() * dshv[:, 27:28].double() * p["sigma.2.weight"].reshape(1, W).to(dev).double()
-    ref["sigma.0.weight"], ref["sigma.0.bias"] = gemm(dy_sigma0, act(D - 1)), dy_sigma0.sum(0).cpu()
+    ref["sigma.0.weight"], ref["sigma.0.bias"] = gemm(dyl(D), act(D - 1)), dyl(D).double().sum(0).cpu()
     ref["sh.0.weight"], ref["sh.0.bias"] = gemm(dyl(D + 1), act(D - 1)), dyl(D + 1).double().sum(0).cpu()
     ref["sh.2.weight"], ref["sh.2.bias"] = gemm(dshv[:, :27], act(D + 1)), dshv[:, :27].double().sum(0).cpu()
     ref["sigma.2.weight"], ref["sigma.2.bias"] = gemm(dshv[:, 27:28], act(D)), dshv[:, 27:28].double().sum(0).cpu()
