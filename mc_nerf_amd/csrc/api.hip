@@ -24,9 +24,11 @@ static int check(const char* where, hipError_t e) {
     return -2;
 }
 static bool net_ok(int depth, int width, int skip) {
-    (void)skip;
-    return depth >= 1 && depth <= MCN_MAXD && (width == 32 || width == 64 || width == 128 || width == 256);
+    if (!(depth >= 1 && depth <= MCN_MAXD && (width == 32 || width == 64 || width == 128 || width == 256))) return false;
+    return skip >= -1 && (skip < MCN_SKIP_MASK || ((skip >> 8) >> depth) == 0);      // -1, a layer index, or a mask of layers < depth
 }
+// the register-chain families (f16 / bf16 / f16x3) take at most one skip layer
+static bool net16_ok(int depth, int width, int skip) { return net_ok(depth, width, skip) && mcn_single_skip(mcn_skip_mask(depth, skip)) != -2; }
 #define REQ(cond, name) do { if (!(cond)) return fail(name, "invalid argument: " #cond); } while (0)
 
 extern "C" {
@@ -212,7 +214,7 @@ long long mcnerf_packed_bytes_16(int depth, int width, int skip, int dtype, int 
 }
 int mcnerf_pack_weights_16(int depth, int width, int skip, const float* params, void* packed_fwd, void* packed_bwd,
                            int dtype, uint32_t* range_flags, void* stream) {
-    REQ(net_ok(depth, width, skip) && params && packed_fwd && packed_bwd && dtype_ok(dtype), "mcnerf_pack_weights_16");
+    REQ(net16_ok(depth, width, skip) && params && packed_fwd && packed_bwd && dtype_ok(dtype), "mcnerf_pack_weights_16");
     if (dtype == 2) return check("mcnerf_pack_weights_16", mcnx3_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, range_flags, (hipStream_t)stream));
     return check("mcnerf_pack_weights_16", mcn16_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, dtype, range_flags, (hipStream_t)stream));
 }
@@ -234,7 +236,7 @@ int mcnerf_mlp_fwd_16(int depth, int width, int skip, int dtype, const float* pa
                       const float* barf_w, const int32_t* idx, const int32_t* count, int max_rows,
                       int n_rays, int S, float* out,
                       void* act_ws, long long capacity, void* enc_ws, uint32_t* mask_ws, void* sh_ws, void* stream) {
-    REQ(net_ok(depth, width, skip) && dtype_ok(dtype), "mcnerf_mlp_fwd_16");
+    REQ(net16_ok(depth, width, skip) && dtype_ok(dtype), "mcnerf_mlp_fwd_16");
     REQ(params && packed_fwd && rays_o && rays_d && zgrid && barf_w && out && n_rays >= 0 && S > 0, "mcnerf_mlp_fwd_16");
     REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_fwd_16");
     REQ(!idx || max_rows >= 0, "mcnerf_mlp_fwd_16");
@@ -257,7 +259,7 @@ int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* pa
                       int n_rays, int S, const float* out, const float* d_out,
                       const uint32_t* mask_ws, long long capacity, const void* enc_ws, const void* sh_ws,
                       void* dy_ws, void* dsh_ws, float* d_rays_o, float* d_rays_d, const uint32_t* gmax_bits, void* stream) {
-    REQ(net_ok(depth, width, skip) && dtype_ok(dtype), "mcnerf_mlp_bwd_16");
+    REQ(net16_ok(depth, width, skip) && dtype_ok(dtype), "mcnerf_mlp_bwd_16");
     REQ(params && packed_bwd && gmax_bits && rays_o && rays_d && zgrid && barf_w && out && d_out && n_rays >= 0 && S > 0, "mcnerf_mlp_bwd_16");
     REQ(mask_ws && enc_ws && sh_ws && dy_ws && dsh_ws, "mcnerf_mlp_bwd_16");
     REQ((idx == nullptr) == (count == nullptr), "mcnerf_mlp_bwd_16");
@@ -276,7 +278,7 @@ int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* pa
 int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const int32_t* count, int rows,
                      const void* act_ws, const void* enc_ws, const void* dy_ws, const void* dsh_ws,
                      long long capacity, float* grads, const uint32_t* gmax_bits, void* stream) {
-    REQ(net_ok(depth, width, skip) && dtype_ok(dtype), "mcnerf_mlp_dw_16");
+    REQ(net16_ok(depth, width, skip) && dtype_ok(dtype), "mcnerf_mlp_dw_16");
     REQ(act_ws && enc_ws && dy_ws && dsh_ws && grads && gmax_bits && rows >= 0 && capacity >= rows, "mcnerf_mlp_dw_16");
     Mcn16DwArgs a;
     a.lay = mcn_make_layout(depth, width, skip);

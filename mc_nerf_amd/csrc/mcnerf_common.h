@@ -26,8 +26,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Offsets (in floats) of every tensor of one CorseFine_NeRF inside (a) the flat parameter buffer and
 // (b) the packed buffer.  Built on the host by mcn_make_layout(), passed to kernels by value.
+// `skip` at the C ABI (include/mcnerf.h): -1 = no skip layer, 0 .. depth-1 = that layer takes [encoding | hidden]
+// (model/net_block.py:55-58, 71), >= MCN_SKIP_MASK = (bit mask of such layers) << 8 -- the reference's `skips` is a list.
+// The exact-fp32 kernel family handles any mask; the register-chain families (f16 / bf16 / f16x3) one skip layer.
+#define MCN_SKIP_MASK 256
+static inline unsigned mcn_skip_mask(int depth, int skip) {
+    if (skip >= MCN_SKIP_MASK) return ((unsigned)skip >> 8) & ((1u << depth) - 1u) & ~1u;      // (layer 0 takes the encoding alone)
+    return (skip > 0 && skip < depth) ? (1u << skip) : 0u;
+}
+// the one skip layer of a mask, -1 for none, -2 for more than one
+static inline int mcn_single_skip(unsigned mask) {
+    if (!mask) return -1;
+    if (mask & (mask - 1)) return -2;
+    int l = 0;
+    while (!((mask >> l) & 1u)) ++l;
+    return l;
+}
+
 struct McnLayout {
-    int depth, width, skip;
+    int depth, width, skip;      // skip: the single skip layer, -1 none, -2 several (skip_mask has them all)
+    unsigned skip_mask;
     // flat parameter buffer (reference order)
     int pW[MCN_MAXD], pB[MCN_MAXD];
     int pWs1, pBs1, pWs2, pBs2, pWc1, pBc1, pWc2, pBc2;
@@ -35,26 +53,32 @@ struct McnLayout {
     // packed, forward orientation: P[ntile][kstep][lane][4] = W[32*ntile + (lane&31)][8*kstep + 4*(lane>>5) + i]
     int fEnc0;               // layer 0, K = 64 (63 padded)
     int fH[MCN_MAXD];        // layers >= 1: the hidden-input segment (K = width)
-    int fEncS;               // skip layer: the encoded-input segment (K = 64)
+    int fEncS[MCN_MAXD];     // skip layers: the encoded-input segment (K = 64)
     int fS1, fC1;            // sigma.0, sh.0
     int fC2;                 // sh.2 (N = 32, 27 padded)
     // packed, transposed orientation (for dX = W^T dY): PT[ktile][nstep][lane][4] = W[8*nstep + 4*(lane>>5) + i][32*ktile + (lane&31)]
-    int bEnc0, bH[MCN_MAXD], bEncS, bS1, bC1, bC2;
+    int bEnc0, bH[MCN_MAXD], bEncS[MCN_MAXD], bS1, bC1, bC2;
     int n_packed;
 };
 
-static inline int mcn_in_features(int depth, int width, int skip, int i) {
+static inline int mcn_in_features(int depth, int width, int skip, int i) {       // (`skip` in the ABI's encoding)
     if (i == 0) return MCN_ENC;
-    return (i == skip) ? width + MCN_ENC : width;
+    return ((mcn_skip_mask(depth, skip) >> i) & 1u) ? width + MCN_ENC : width;
+}
+
+static inline int mcn_layer_in(unsigned skip_mask, int width, int i) {              // input features of trunk layer i
+    return i == 0 ? MCN_ENC : (((skip_mask >> i) & 1u) ? width + MCN_ENC : width);
 }
 
 static inline McnLayout mcn_make_layout(int depth, int width, int skip) {
     McnLayout L;
-    L.depth = depth; L.width = width; L.skip = skip;
+    L.depth = depth; L.width = width;
+    L.skip_mask = mcn_skip_mask(depth, skip);
+    L.skip = mcn_single_skip(L.skip_mask);
     int o = 0;
     // every tensor starts on a 16-byte boundary so that float4 loads of biases / weight rows are aligned
     auto al = [&o]() { o = (o + 3) & ~3; return o; };
-    for (int i = 0; i < MCN_MAXD; ++i) { L.pW[i] = L.pB[i] = 0; L.fH[i] = L.bH[i] = 0; }
+    for (int i = 0; i < MCN_MAXD; ++i) { L.pW[i] = L.pB[i] = 0; L.fH[i] = L.bH[i] = 0; L.fEncS[i] = L.bEncS[i] = 0; }
     for (int i = 0; i < depth; ++i) {
         L.pW[i] = al(); o += width * mcn_in_features(depth, width, skip, i);
         L.pB[i] = al(); o += width;
@@ -68,13 +92,22 @@ static inline McnLayout mcn_make_layout(int depth, int width, int skip) {
     int q = 0;
     L.fEnc0 = q; q += width * MCN_ENCP;
     for (int i = 1; i < depth; ++i) { L.fH[i] = q; q += width * width; }
-    L.fEncS = q; q += width * MCN_ENCP;
+    {   // (one encoded-input segment per skip layer; a net without a skip layer keeps one unused slot: the packed size of the
+        //  single-skip nets is what it always was)
+        int any = 0;
+        for (int i = 1; i < depth; ++i) if ((L.skip_mask >> i) & 1u) { L.fEncS[i] = q; q += width * MCN_ENCP; any = 1; }
+        if (!any) q += width * MCN_ENCP;
+    }
     L.fS1 = q; q += width * width;
     L.fC1 = q; q += width * width;
     L.fC2 = q; q += MCN_NSHP * width;
     L.bEnc0 = q; q += width * MCN_ENCP;
     for (int i = 1; i < depth; ++i) { L.bH[i] = q; q += width * width; }
-    L.bEncS = q; q += width * MCN_ENCP;
+    {
+        int any = 0;
+        for (int i = 1; i < depth; ++i) if ((L.skip_mask >> i) & 1u) { L.bEncS[i] = q; q += width * MCN_ENCP; any = 1; }
+        if (!any) q += width * MCN_ENCP;
+    }
     L.bS1 = q; q += width * width;
     L.bC1 = q; q += width * width;
     L.bC2 = q; q += MCN_NSHP * width;

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     f32x16 denc2[1][1];                                // second tile when ENC_TILES > WAVES
     mcn_zero<1, 1>(denc2);
     for (int l = D - 1; l >= 0; --l) {
-        if (l == 0 || l == L.skip) {
-            const f32x4* pe = pk + ((l == 0 ? L.bEnc0 : L.bEncS) >> 2);
+        if (l == 0 || ((L.skip_mask >> l) & 1u)) {
+            const f32x4* pe = pk + ((l == 0 ? L.bEnc0 : L.bEncS[l]) >> 2);
             {
                 const int t = wave;
                 if (t < ENC_TILES) mcn_gemm_seg<1, 1>(denc, X, XW, (t >> 1) * 32, 0, NSH, pe + (t & 1) * NSH * 64, lane);

@@ -170,11 +170,11 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_ENCP / 8, pk + (L.fEnc0 >> 2) + (wn * NI) * (MCN_ENCP / 8) * 64, lane);
         } else {
             mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, KSH, pk + (L.fH[l] >> 2) + (wn * NI) * KSH * 64, lane);
-            if (l == L.skip) {
+            if ((L.skip_mask >> l) & 1u) {
                 __syncthreads();                       // everyone finished reading h from X
                 write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT, a.enc_in, row0, total);
                 __syncthreads();
-                mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_ENCP / 8, pk + (L.fEncS >> 2) + (wn * NI) * (MCN_ENCP / 8) * 64, lane);
+                mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_ENCP / 8, pk + (L.fEncS[l] >> 2) + (wn * NI) * (MCN_ENCP / 8) * 64, lane);
             }
         }
         __syncthreads();

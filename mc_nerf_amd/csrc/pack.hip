@@ -13,7 +13,7 @@ struct PackSeg {
 struct PackTable {
     int nseg;
     int total4;              // float4 count of one orientation
-    PackSeg seg[16];
+    PackSeg seg[2 * MCN_MAXD + 4];
 };
 
 __global__ void pack_kernel(PackTable t, const float* __restrict__ params, float* __restrict__ packed) {
@@ -75,8 +75,8 @@ static void build_pack_table(const McnLayout& L, PackTable& t) {
     const int W = L.width;
     add(L.pW[0], MCN_ENC, 0, W, MCN_ENC, W, MCN_ENCP, L.fEnc0, L.bEnc0);
     for (int i = 1; i < L.depth; ++i) {
-        if (i == L.skip) {
-            add(L.pW[i], W + MCN_ENC, 0, W, MCN_ENC, W, MCN_ENCP, L.fEncS, L.bEncS);
+        if ((L.skip_mask >> i) & 1u) {
+            add(L.pW[i], W + MCN_ENC, 0, W, MCN_ENC, W, MCN_ENCP, L.fEncS[i], L.bEncS[i]);
             add(L.pW[i], W + MCN_ENC, MCN_ENC, W, W, W, W, L.fH[i], L.bH[i]);
         } else {
             add(L.pW[i], W, 0, W, W, W, W, L.fH[i], L.bH[i]);

@@ -130,10 +130,9 @@ class CorseFine_NeRF(nn.Module):
         self.depth = sys_params[f"{key}_MLP_depth"]
         self.width = sys_params[f"{key}_MLP_width"]
         self.skips = list(sys_params[f"{key}_MLP_skip"])
-        skips = [s for s in self.skips if 0 < s < self.depth]
-        if len(skips) > 1:
-            raise ValueError("at most one skip layer is supported by the HIP kernels")
-        self.net = ops.Net(self.depth, self.width, skips[0] if skips else -1)
+        # any `skips` list (reference :45, 55-58); more than one skip layer runs on the exact-fp32 kernel family only
+        # (NeRF_Model refuses the register-chain precision modes for such a net)
+        self.net = ops.Net(self.depth, self.width, ops.skip_code(self.skips, self.depth))
         for i in range(self.depth):
             fan_in = self.net.in_features(i)
             setattr(self, f"xyz_encoding_{i+1}", nn.Sequential(nn.Linear(fan_in, self.width), nn.ReLU(True)))

@@ -16,9 +16,24 @@ from . import _lib
 Tensor = torch.Tensor
 
 
+SKIP_MASK = 256          # MCN_SKIP_MASK: skip >= 256 = (bit mask of skip layers) << 8 (include/mcnerf.h)
+
+
+def skip_code(skips, depth: int) -> int:
+    """The reference's `skips` list (model/net_block.py:45) -> the C ABI's `skip` argument: -1 (none), the layer index (one),
+    or a bit mask << 8 (several: exact-fp32 kernels only)."""
+    ks = sorted({int(k) for k in skips if 0 < int(k) < depth})
+    if not ks:
+        return -1
+    if len(ks) == 1:
+        return ks[0]
+    return sum(1 << k for k in ks) << 8
+
+
 @dataclass(frozen=True)
 class Net:
-    """(depth, width, skip) of one CorseFine_NeRF (model/net_block.py:40-49 in the reference)."""
+    """(depth, width, skip) of one CorseFine_NeRF (model/net_block.py:40-49 in the reference); `skip` in the C ABI's encoding
+    (`skip_code`)."""
     depth: int
     width: int
     skip: int
@@ -27,10 +42,20 @@ class Net:
     def triple(self):
         return (self.depth, self.width, self.skip)
 
+    @property
+    def skips(self):
+        if self.skip >= SKIP_MASK:
+            return [l for l in range(self.depth) if (self.skip >> 8) >> l & 1]
+        return [self.skip] if 0 < self.skip < self.depth else []
+
+    @property
+    def multi_skip(self) -> bool:
+        return len(self.skips) > 1
+
     def in_features(self, i: int) -> int:
         if i == 0:
             return 63
-        return self.width + 63 if i == self.skip else self.width
+        return self.width + 63 if i in self.skips else self.width
 
     def shapes(self):
         """Tensor shapes in the reference's state-dict order."""

@@ -30,7 +30,8 @@ def cfg_from_golden(g):
     """Rebuild the oracle RenderCfg from a fixture's packed ``cfg`` / ``barf`` arrays."""
     from oracle import mcnerf_oracle as O
     c = [int(v) for v in g["cfg"]]
-    kw = dict(samples=c[0], scale=c[1], coarse=O.NetCfg(c[2], c[3], (c[4],)), fine=O.NetCfg(c[5], c[6], (c[7],)),
+    sk = lambda key, first: tuple(int(v) for v in g[key]) if key in g else (first,)      # (fixtures of multi-skip nets carry the whole lists)
+    kw = dict(samples=c[0], scale=c[1], coarse=O.NetCfg(c[2], c[3], sk("skips_c", c[4])), fine=O.NetCfg(c[5], c[6], sk("skips_f", c[7])),
               barf_mode=bool(c[8]))
     if "barf" in g:
         kw.update(barf_start=float(g["barf"][0]), barf_end=float(g["barf"][1]))

@@ -194,7 +194,8 @@ def g7_train(tag, cfg: O.RenderCfg, n, seed, step_r, sigma_shift=0.0, only_coars
                 seed_f=seed + 200, sigma_shift=sigma_shift,
                 cfg=np.array([cfg.samples, cfg.scale, cfg.coarse.depth, cfg.coarse.width, cfg.coarse.skips[0],
                               cfg.fine.depth, cfg.fine.width, cfg.fine.skips[0], int(cfg.barf_mode)]),
-                barf=np.array([cfg.barf_start, cfg.barf_end]))
+                barf=np.array([cfg.barf_start, cfg.barf_end]),
+                skips_c=np.array(cfg.coarse.skips), skips_f=np.array(cfg.fine.skips))      # (the whole `skips` lists; `cfg` holds the first entries)
     if only_coarse:
         arrs["depth_c"] = depth_c
     else:
@@ -382,10 +383,19 @@ def g7_full_size():
     print(f"reference's own reorder noise at {n} rays: worst {worst[0]:.1e} of its tensor's max ({worst[1][10:]}), rgb {z['noise_abs.rgb_f']:.1e}")
 
 
+def g7_multi_skip():
+    """General topology: `skips` lists with several entries (model/net_block.py:45, 55-58, 71) -- coarse 4 x 32 with the encoding
+    re-concatenated at layers 1 and 3, fine 8 x 64 at layers 2, 4 and 6; one train render + backward of the actual reference."""
+    g7_train("g7_train_s32x2_multiskip", O.RenderCfg(samples=32, scale=2, coarse=O.NetCfg(4, 32, (1, 3)), fine=O.NetCfg(8, 64, (2, 4, 6))), 80, 76, 1.0)
+
+
 def main():
     torch.set_num_threads(4)
     if "--only-full-size" in sys.argv:
         return g7_full_size()
+    if "--only-multi-skip" in sys.argv:
+        return g7_multi_skip()
+    g7_multi_skip()
     g7_full_size()
     g11_mc_model_step()
     g11_mc_model_step("CAM_PARAM_EPOCH", "g11b_mc_model_cam_param", extr_shift=0.7)

@@ -82,6 +82,52 @@ def test_render_rays_train_matches_reference(gpu_device, name, precision):
     assert checked == len(list(m.nerf_coarse.parameters())) + len(list(m.nerf_fine.parameters()))
 
 
+def test_multi_skip_topology_matches_reference(gpu_device):
+    """General topology (reference: `skips` is a list, model/net_block.py:45, 55-58, 71): coarse 4 x 32 with the encoding
+    re-concatenated at layers 1 and 3, fine 8 x 64 at layers 2, 4 and 6 -- train render + backward against the golden captured
+    from the actual reference, on the exact-fp32 kernel family (the one that takes any skip mask); the register-chain
+    precision modes refuse such a net at construction."""
+    from mc_nerf_amd.model import MC_NeRF_Loss, NeRF_Model
+    g = load_golden("g7_train_s32x2_multiskip")
+    dev = gpu_device
+    m, cfg, pc, pf = build_model(g, dev, precision="f32")
+    assert cfg.coarse.skips == (1, 3) and cfg.fine.skips == (2, 4, 6) and m.nerf_fine.net.multi_skip
+    assert m.nerf_fine.xyz_encoding_5[0].weight.shape == (64, 64 + 63) and m.nerf_fine.xyz_encoding_4[0].weight.shape == (64, 64)
+    d = t(g["rays_d"]).to(dev).requires_grad_(True)
+    o = t(g["rays_o"]).to(dev).requires_grad_(True)
+    rgb_c, rgb_f = m.render_rays_train(d, o, 0, float(g["step_r"]), jitter=t(g["jitter"]).to(dev), eps_c=t(g["eps_c"]).to(dev),
+                                       eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
+    assert err(rgb_c, g["rgb_c"]) < TOL and err(rgb_f, g["rgb_f"]) < TOL
+    loss = MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([rgb_c, rgb_f, t(g["gt"]).to(dev)])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    assert err(d.grad, g["d_rays_d"]) < 1e-4 * max(1.0, float(np.abs(g["d_rays_d"]).max()))
+    assert err(o.grad, g["d_rays_o"]) < 1e-4 * max(1.0, float(np.abs(g["d_rays_o"]).max()))
+    checked, worst = 0, 0.0
+    for tag, net in (("c", m.nerf_coarse), ("f", m.nerf_fine)):
+        for k_, p in net.named_parameters():
+            ref = g[f"g{tag}.{k_}"] if f"g{tag}.{k_}" in g else None
+            if ref is not None:
+                e = err(p.grad, ref) / float(np.abs(ref).max())
+            else:
+                ref = g[f"gsamp{tag}.{k_}"]
+                e = err(p.grad.reshape(-1)[::97], ref) / float(np.abs(ref).max())
+            worst = max(worst, e)
+            assert e < 1e-4, (tag, k_, e)
+            checked += 1
+    assert checked == 2 * (4 + 8) + 16
+    print(f"multi-skip nets (coarse [1, 3], fine [2, 4, 6]) vs the reference's golden: rgb {max(err(rgb_c, g['rgb_c']), err(rgb_f, g['rgb_f'])):.1e}, worst gradient {worst:.1e} of its tensor's max")
+    # no-grad render path of the same nets
+    with torch.no_grad():
+        r = O.render_rays_test(pc, pf, cfg, t(g["rays_d"]), t(g["rays_o"]), t(g["eps_c"]), t(g["eps_sel"]), t(g["eps_f"]))
+        rgb, depth, opacity = m.render_rays_test(t(g["rays_d"]).to(dev), t(g["rays_o"]).to(dev), m.nerf_coarse, m.nerf_fine,
+                                                 eps_c=t(g["eps_c"]).to(dev), eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
+    assert float((rgb.cpu() - r["rgb"]).abs().max()) < TOL and float((depth.cpu() - r["depth"]).abs().max()) < TOL
+    for precision in ("f16x3", "f16", "bf16"):
+        with pytest.raises(ValueError, match="more than one skip layer"):
+            NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision=precision))
+
+
 # per mode: (rgb abs, worst per-tensor gradient error as a multiple of the reference's own worst reorder noise, median over the
 # tensors likewise against the noise's median) -- measured f32 0.8 / 1.2, f16x3 1.8 / 16 (DESIGN.md 4), f16 / bf16 their operand rounding
 FULL_TOL = {"f32": (1e-4, 2.0, 3.0), "f16x3": (1e-4, 4.0, 40.0), "f16": (5e-5, 60.0, 1500.0), "bf16": (4e-4, 300.0, 8000.0)}
