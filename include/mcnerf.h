@@ -16,9 +16,12 @@
  *   - a net is described by (depth, width, skip): `depth` trunk layers of `width` units with the
  *     encoded input re-concatenated ([x_enc, h]) at layer index `skip` (model/net_block.py:51-59);
  *     widths 32, 64, 128, 256 and depth <= 8 are built.  `skip`: -1 = none, 0 < skip < depth = that
- *     layer, skip >= 256 = (bit mask of such layers) << 8 -- the reference's `skips` is a list
- *     (model/net_block.py:45, 55-58): the exact-fp32 entry points take any mask, the `_16` entry
- *     points (f16 / bf16 / f16x3 register chains) at most one skip layer;
+ *     layer, skip >= 256 = the mask form: bits 8 + l set for every such layer l (bit 8 itself, layer 0,
+ *     is ignored and may serve as the marker of the form) -- the reference's `skips` is a list
+ *     (model/net_block.py:45, 55-58) -- and, when bit 7 is set, the SH degree of the colour head in
+ *     bits 4..6 (`MLP_deg` 0 .. 3, model/net_block.py:43, 75-76; 3 (deg + 1)^2 sh.2 outputs; default 2).
+ *     The exact-fp32 entry points take any mask and degree, the `_16` entry points (f16 / bf16 / f16x3
+ *     register chains) at most one skip layer and degree 2;
  *   - parameters of one net live in ONE flat fp32 buffer in the reference's state-dict order
  *     (xyz_encoding_{1..depth}.0.{weight,bias}, sigma.0.*, sigma.2.*, sh.0.*, sh.2.*), Linear weights
  *     [out][in] row-major; gradients use the same layout.

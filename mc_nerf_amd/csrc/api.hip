@@ -25,10 +25,14 @@ static int check(const char* where, hipError_t e) {
 }
 static bool net_ok(int depth, int width, int skip) {
     if (!(depth >= 1 && depth <= MCN_MAXD && (width == 32 || width == 64 || width == 128 || width == 256))) return false;
-    return skip >= -1 && (skip < MCN_SKIP_MASK || ((skip >> 8) >> depth) == 0);      // -1, a layer index, or a mask of layers < depth
+    if (skip < -1) return false;
+    if (skip >= MCN_SKIP_MASK && ((skip >> 8) >> depth) != 0) return false;          // -1, a layer index, or a mask of layers < depth
+    return mcn_topo_deg(skip) <= MCN_MAXDEG;
 }
-// the register-chain families (f16 / bf16 / f16x3) take at most one skip layer
-static bool net16_ok(int depth, int width, int skip) { return net_ok(depth, width, skip) && mcn_single_skip(mcn_skip_mask(depth, skip)) != -2; }
+// the register-chain families (f16 / bf16 / f16x3) take at most one skip layer and SH degree 2
+static bool net16_ok(int depth, int width, int skip) {
+    return net_ok(depth, width, skip) && mcn_single_skip(mcn_skip_mask(depth, skip)) != -2 && mcn_topo_deg(skip) == 2;
+}
 #define REQ(cond, name) do { if (!(cond)) return fail(name, "invalid argument: " #cond); } while (0)
 
 extern "C" {

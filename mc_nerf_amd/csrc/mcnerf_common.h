@@ -18,8 +18,10 @@
 #define MCN_ENC 63          // 3 + 3*2*10 encoded channels (model/net_block.py:17)
 #define MCN_ENCP 64         // padded
 #define MCN_NFREQ 10
-#define MCN_NSH 27          // 3 * (deg+1)^2, deg = 2
+#define MCN_NSH 27          // 3 * (deg+1)^2 at deg = 2 (the register-chain families; the exact-fp32 family takes L.nsh)
 #define MCN_NSHP 32
+#define MCN_MAXDEG 3        // SH degrees 0 .. 3 (model/net_utils.py:103-191; 3, 12, 27, 48 sh.2 outputs)
+#define MCN_NBMAX 16        // (MAXDEG + 1)^2 basis functions
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -29,7 +31,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // `skip` at the C ABI (include/mcnerf.h): -1 = no skip layer, 0 .. depth-1 = that layer takes [encoding | hidden]
 // (model/net_block.py:55-58, 71), >= MCN_SKIP_MASK = (bit mask of such layers) << 8 -- the reference's `skips` is a list.
 // The exact-fp32 kernel family handles any mask; the register-chain families (f16 / bf16 / f16x3) one skip layer.
+// In the mask form the low byte may also carry the SH degree of the colour head (`MLP_deg`, model/net_block.py:43, 75-76):
+// bit 7 set -> bits 4..6 = degree (0 .. 3); otherwise (and in the index forms) the degree is 2.  Degrees other than 2: exact-fp32
+// family only.
 #define MCN_SKIP_MASK 256
+#define MCN_TOPO_HAS_DEG 0x80
+static inline int mcn_topo_deg(int skip) { return (skip >= MCN_SKIP_MASK && (skip & MCN_TOPO_HAS_DEG)) ? ((skip >> 4) & 7) : 2; }
 static inline unsigned mcn_skip_mask(int depth, int skip) {
     if (skip >= MCN_SKIP_MASK) return ((unsigned)skip >> 8) & ((1u << depth) - 1u) & ~1u;      // (layer 0 takes the encoding alone)
     return (skip > 0 && skip < depth) ? (1u << skip) : 0u;
@@ -46,6 +53,7 @@ static inline int mcn_single_skip(unsigned mask) {
 struct McnLayout {
     int depth, width, skip;      // skip: the single skip layer, -1 none, -2 several (skip_mask has them all)
     unsigned skip_mask;
+    int sh_deg, nb, nsh, nshp;   // SH degree, (deg + 1)^2 basis functions, 3 nb outputs of sh.2, padded to 32 / 64 (+ 1 spare column for d sigma)
     // flat parameter buffer (reference order)
     int pW[MCN_MAXD], pB[MCN_MAXD];
     int pWs1, pBs1, pWs2, pBs2, pWc1, pBc1, pWc2, pBc2;
@@ -75,6 +83,10 @@ static inline McnLayout mcn_make_layout(int depth, int width, int skip) {
     L.depth = depth; L.width = width;
     L.skip_mask = mcn_skip_mask(depth, skip);
     L.skip = mcn_single_skip(L.skip_mask);
+    L.sh_deg = mcn_topo_deg(skip);
+    L.nb = (L.sh_deg + 1) * (L.sh_deg + 1);
+    L.nsh = 3 * L.nb;
+    L.nshp = L.nsh < 32 ? 32 : 64;
     int o = 0;
     // every tensor starts on a 16-byte boundary so that float4 loads of biases / weight rows are aligned
     auto al = [&o]() { o = (o + 3) & ~3; return o; };
@@ -86,7 +98,7 @@ static inline McnLayout mcn_make_layout(int depth, int width, int skip) {
     L.pWs1 = al(); o += width * width; L.pBs1 = al(); o += width;
     L.pWs2 = al(); o += width;         L.pBs2 = al(); o += 1;
     L.pWc1 = al(); o += width * width; L.pBc1 = al(); o += width;
-    L.pWc2 = al(); o += MCN_NSH * width; L.pBc2 = al(); o += MCN_NSH;
+    L.pWc2 = al(); o += L.nsh * width; L.pBc2 = al(); o += L.nsh;
     al();
     L.n_params = o;
     int q = 0;
@@ -100,7 +112,7 @@ static inline McnLayout mcn_make_layout(int depth, int width, int skip) {
     }
     L.fS1 = q; q += width * width;
     L.fC1 = q; q += width * width;
-    L.fC2 = q; q += MCN_NSHP * width;
+    L.fC2 = q; q += L.nshp * width;
     L.bEnc0 = q; q += width * MCN_ENCP;
     for (int i = 1; i < depth; ++i) { L.bH[i] = q; q += width * width; }
     {
@@ -110,7 +122,7 @@ static inline McnLayout mcn_make_layout(int depth, int width, int skip) {
     }
     L.bS1 = q; q += width * width;
     L.bC1 = q; q += width * width;
-    L.bC2 = q; q += MCN_NSHP * width;
+    L.bC2 = q; q += L.nshp * width;
     L.n_packed = q;
     return L;
 }
@@ -229,5 +241,53 @@ __device__ __forceinline__ void mcn_sh_basis(float x, float y, float z, float (&
     b[4] = C20 * (x * y); b[5] = -C20 * (y * z);
     b[6] = C22 * (2.0f * z * z - x * x - y * y);
     b[7] = -C20 * (x * z); b[8] = C24 * (x * x - y * y);
+}
+// The signed SH basis factors of eval_sh up to degree 3 (model/net_utils.py:152-179; the same association as the reference's
+// expressions: (C * a) * (polynomial)), zero beyond (deg + 1)^2, and their derivatives with respect to the direction.
+__device__ __forceinline__ void mcn_sh_basis16(int deg, float x, float y, float z, float (&b)[MCN_NBMAX]) {
+#pragma unroll
+    for (int i = 0; i < MCN_NBMAX; ++i) b[i] = 0.f;
+    float b9[9];
+    mcn_sh_basis(x, y, z, b9);
+    b[0] = b9[0];
+    if (deg >= 1) { b[1] = b9[1]; b[2] = b9[2]; b[3] = b9[3]; }
+    if (deg >= 2) { b[4] = b9[4]; b[5] = b9[5]; b[6] = b9[6]; b[7] = b9[7]; b[8] = b9[8]; }
+    if (deg >= 3) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float C30 = -0.5900435899266435f, C31 = 2.890611442640554f, C32 = -0.4570457994644658f, C33 = 0.3731763325901154f,
+                    C35 = 1.445305721320277f;
+        b[9] = C30 * y * (3.f * xx - yy);
+        b[10] = C31 * (x * y) * z;
+        b[11] = C32 * y * (4.f * zz - xx - yy);
+        b[12] = C33 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+        b[13] = C32 * x * (4.f * zz - xx - yy);
+        b[14] = C35 * z * (xx - yy);
+        b[15] = C30 * x * (xx - 3.f * yy);
+    }
+}
+__device__ __forceinline__ void mcn_sh_dbasis16(int deg, float x, float y, float z, float (&gx)[MCN_NBMAX], float (&gy)[MCN_NBMAX], float (&gz)[MCN_NBMAX]) {
+#pragma unroll
+    for (int i = 0; i < MCN_NBMAX; ++i) { gx[i] = 0.f; gy[i] = 0.f; gz[i] = 0.f; }
+    const float C1 = 0.4886025119029199f, C20 = 1.0925484305920792f, C22 = 0.31539156525252005f, C24 = 0.5462742152960396f;
+    if (deg >= 1) { gy[1] = -C1; gz[2] = C1; gx[3] = -C1; }
+    if (deg >= 2) {
+        gx[4] = C20 * y; gy[4] = C20 * x;
+        gy[5] = -C20 * z; gz[5] = -C20 * y;
+        gx[6] = -2.f * C22 * x; gy[6] = -2.f * C22 * y; gz[6] = 4.f * C22 * z;
+        gx[7] = -C20 * z; gz[7] = -C20 * x;
+        gx[8] = 2.f * C24 * x; gy[8] = -2.f * C24 * y;
+    }
+    if (deg >= 3) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float C30 = -0.5900435899266435f, C31 = 2.890611442640554f, C32 = -0.4570457994644658f, C33 = 0.3731763325901154f,
+                    C35 = 1.445305721320277f;
+        gx[9] = C30 * 6.f * x * y;           gy[9] = C30 * (3.f * xx - 3.f * yy);
+        gx[10] = C31 * y * z;                gy[10] = C31 * x * z;                         gz[10] = C31 * x * y;
+        gx[11] = C32 * (-2.f * x * y);       gy[11] = C32 * (4.f * zz - xx - 3.f * yy);    gz[11] = C32 * 8.f * y * z;
+        gx[12] = C33 * (-6.f * x * z);       gy[12] = C33 * (-6.f * y * z);                gz[12] = C33 * (6.f * zz - 3.f * xx - 3.f * yy);
+        gx[13] = C32 * (4.f * zz - 3.f * xx - yy); gy[13] = C32 * (-2.f * x * y);          gz[13] = C32 * 8.f * x * z;
+        gx[14] = C35 * 2.f * x * z;          gy[14] = C35 * (-2.f * y * z);                gz[14] = C35 * (xx - yy);
+        gx[15] = C30 * (3.f * xx - 3.f * yy); gy[15] = C30 * (-6.f * x * y);
+    }
 }
 #endif  // __HIPCC__

@@ -62,6 +62,55 @@ __device__ __forceinline__ void mask_store(f32x16 (&acc)[NI][MI], const unsigned
         }
 }
 
+// Per-sample prologue for an SH degree other than 2 (templated on the degree: every index is a constant): sigmoid and SH
+// backward -> the dY row of sh.2 (3 (DEG + 1)^2 columns, d sigma in the spare column after them) into the X tile and dsh_save,
+// d sigma, d colour / d direction through the basis derivatives (model/net_utils.py:152-179).
+template <int WIDTH, int DEG>
+__device__ __forceinline__ void mcn_sh_bwd_general(const McnMlpBwdArgs& a, float* X, int xw, int m, long long g, long long total,
+                                                   float* sdsig, float* sddir, int* sray, float* sz) {
+    constexpr int NB = (DEG + 1) * (DEG + 1), NSH = 3 * NB, NSHP = NSH < 32 ? 32 : 64;
+    float dsg = 0.f, ddx = 0.f, ddy = 0.f, ddz = 0.f, zv = 0.f;
+    int ray = -1;
+    float dpre[3] = {0.f, 0.f, 0.f};
+    float b[MCN_NBMAX];
+#pragma unroll
+    for (int i = 0; i < MCN_NBMAX; ++i) b[i] = 0.f;
+    if (g < total) {
+        int j;
+        if (a.idx) { const int2 rj = a.idx[g]; ray = rj.x; j = rj.y; }
+        else { ray = (int)(g / a.S); j = (int)(g - (long long)ray * a.S); }
+        zv = a.zgrid[j];
+        if (a.jitter) zv = __fadd_rn(zv, a.jitter[ray]);
+        const size_t addr = (size_t)ray * a.S + j;
+        const f32x4 o = *reinterpret_cast<const f32x4*>(a.out + addr * 4);
+        const f32x4 go = *reinterpret_cast<const f32x4*>(a.d_out + addr * 4);
+        dsg = go[0];
+        const float x = a.rays_d[ray * 3], y = a.rays_d[ray * 3 + 1], z = a.rays_d[ray * 3 + 2];
+        mcn_sh_basis16(DEG, x, y, z, b);
+        float gx[MCN_NBMAX], gy[MCN_NBMAX], gz[MCN_NBMAX];
+        mcn_sh_dbasis16(DEG, x, y, z, gx, gy, gz);
+        const float* sh = a.sh_save + (size_t)g * NSHP;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dpre[c] = go[1 + c] * o[1 + c] * (1.f - o[1 + c]);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const float s = sh[NB * c + i];
+                ddx += dpre[c] * (gx[i] * s); ddy += dpre[c] * (gy[i] * s); ddz += dpre[c] * (gz[i] * s);
+            }
+        }
+    }
+    float* dst = g < total ? a.dsh_save + (size_t)g * NSHP : nullptr;
+#pragma unroll
+    for (int n = 0; n < NSHP; ++n) {
+        const float v = n < NSH ? dpre[n / NB] * b[n % NB] : (n == NSH ? dsg : 0.f);
+        X[mcn_swz(m, n, xw)] = v;
+        if (dst) dst[n] = v;
+    }
+    sdsig[m] = dsg; sray[m] = ray; sz[m] = zv;
+    sddir[m * 4] = ddx; sddir[m * 4 + 1] = ddy; sddir[m * 4 + 2] = ddz; sddir[m * 4 + 3] = 0.f;
+}
+
 template <int WIDTH>
 __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) void mlp_bwd_kernel(McnMlpBwdArgs a) {
     using G = McnGeom<WIDTH>;
@@ -92,6 +141,14 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     // ---- per-sample prologue: sigmoid and SH backward -> dsh (the dY of sh.2), d sigma, d dir
     for (int m = tid; m < MT; m += NT) {
         const long long g = row0 + m;
+        if (L.sh_deg != 2) {          // (block-uniform) general SH degree
+            switch (L.sh_deg) {
+                case 0: mcn_sh_bwd_general<WIDTH, 0>(a, X, XW, m, g, total, sdsig, sddir, sray, sz); break;
+                case 1: mcn_sh_bwd_general<WIDTH, 1>(a, X, XW, m, g, total, sdsig, sddir, sray, sz); break;
+                default: mcn_sh_bwd_general<WIDTH, 3>(a, X, XW, m, g, total, sdsig, sddir, sray, sz); break;
+            }
+            continue;
+        }
         __attribute__((aligned(16))) float dsh[MCN_NSHP];
 #pragma unroll
         for (int i = 0; i < MCN_NSHP; ++i) dsh[i] = 0.f;
@@ -143,7 +200,7 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     f32x16 acc[NI][MI];
     // ---- sh.2^T : dsh [MT][32] -> d hc ; mask with hc -> dY of sh.0
     mcn_zero<NI, MI>(acc);
-    mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_NSHP / 8, pk + (L.bC2 >> 2) + (wn * NI) * (MCN_NSHP / 8) * 64, lane);
+    mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, L.nshp / 8, pk + (L.bC2 >> 2) + (wn * NI) * (L.nshp / 8) * 64, lane);
     __syncthreads();
     mask_store<WIDTH, NI, MI>(acc, a.mask_save + (size_t)(D + 1) * (AS / 32), a.dy_save + (size_t)(D + 1) * AS, X, XW, mrow0, ncol0, row0, total, lane);
     __syncthreads();

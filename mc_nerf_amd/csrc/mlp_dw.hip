@@ -261,10 +261,16 @@ hipError_t mcn_launch_dw(const McnDwArgs& a, hipStream_t st) {
         if ((e = launch_seg(s1, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
         DwSeg c1 = {dy(D + 1), W, act(D - 1), W, W, 0, W, W, W, a.grads + L.pWc1, W, a.grads + L.pBc1};
         if ((e = launch_seg(c1, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
-        DwSeg c2 = {a.dsh_save, MCN_NSHP, act(D + 1), W, MCN_NSHP, 0, MCN_NSH, W, W, a.grads + L.pWc2, W, a.grads + L.pBc2};
-        if ((e = launch_seg(c2, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
-        // sigma.2 (1 x W): d sigma sits in the spare column 27 of dsh_save, its input is the sigma hidden layer
-        DwSeg s2 = {a.dsh_save, MCN_NSHP, act(D), W, MCN_NSHP, MCN_NSH, MCN_NSH + 1, W, W, a.grads + L.pWs2, W, a.grads + L.pBs2};
+        // sh.2: nsh = 3 (deg + 1)^2 outputs in rows of nshp floats (32, or 64 at degree 3: two 32-column halves of the same rows)
+        const int NP_ = L.nshp, NS_ = L.nsh;
+        for (int half = 0; half * 32 < NP_; ++half) {
+            const int real = NS_ - 32 * half < 32 ? NS_ - 32 * half : 32;
+            if (real <= 0) break;
+            DwSeg c2 = {a.dsh_save + 32 * half, NP_, act(D + 1), W, 32, 0, real, W, W, a.grads + L.pWc2 + (size_t)32 * half * W, W, a.grads + L.pBc2 + 32 * half};
+            if ((e = launch_seg(c2, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
+        }
+        // sigma.2 (1 x W): d sigma sits in the spare column nsh of dsh_save (27 at degree 2), its input is the sigma hidden layer
+        DwSeg s2 = {a.dsh_save + 32 * (NS_ / 32), NP_, act(D), W, 32, NS_ % 32, NS_ % 32 + 1, W, W, a.grads + L.pWs2, W, a.grads + L.pBs2};
         if ((e = launch_seg(s2, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
     }
     return hipSuccess;

@@ -102,6 +102,66 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NI][MI], const floa
         }
 }
 
+// SH output layer + per-sample epilogue for an SH degree other than 2 (`MLP_deg`, model/net_block.py:43, 75-76; eval_sh,
+// model/net_utils.py:103-191): 3 (DEG + 1)^2 outputs in one or two 32-row tiles of sh.2, each through the same [MT][33] LDS
+// buffer; the colour pre-activations accumulate over the coefficients in index order, as the reference's expression does.
+// (The degree-2 path of the kernel is untouched: same code, same summation order, same LDS budget.)
+template <int WIDTH, bool SAVE, int DEG>
+__device__ __forceinline__ void mcn_sh_head_general(const McnMlpFwdArgs& a, const float* X, float* ssh, const float* ssig, const float* sdir,
+                                                    const int* saddr, const f32x4* __restrict__ pk, const float* __restrict__ prm,
+                                                    long long row0, long long total, int tid, int lane, int wave) {
+    using G = McnGeom<WIDTH>;
+    using SM = FwdSmem<WIDTH>;
+    constexpr int MT = SM::MT, XW = SM::XW, WN = G::WN, NT = SM::NT, WAVES = NT / 64, KSH = WIDTH / 8;
+    constexpr int NB = (DEG + 1) * (DEG + 1), NSH = 3 * NB, TILES = NSH <= 32 ? 1 : 2, NSHP = 32 * TILES;
+    static_assert(MT <= NT, "one sample per thread");
+    const McnLayout& L = a.lay;
+    const int r = lane & 31, h = lane >> 5;
+    const int m = tid;
+    const bool mine = m < MT && row0 + m < total;
+    float b[MCN_NBMAX];
+    float pre[3] = {0.f, 0.f, 0.f};
+    if (mine) mcn_sh_basis16(DEG, sdir[m * 4 + 0], sdir[m * 4 + 1], sdir[m * 4 + 2], b);
+#pragma unroll
+    for (int nt = 0; nt < TILES; ++nt) {
+        for (int mt = wave; mt < MT / 32; mt += WAVES) {
+            f32x16 a1[1][1];
+            mcn_zero<1, 1>(a1);
+            mcn_gemm_seg<1, 1>(a1, X, XW, mt * 32, 0, KSH, pk + (L.fC2 >> 2) + nt * KSH * 64, lane);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = (e & 3) + 8 * (e >> 2) + 4 * h;
+                ssh[(mt * 32 + r) * 33 + n] = a1[0][0][e];
+            }
+        }
+        __syncthreads();
+        if (mine) {
+            float* dst = SAVE ? a.sh_save + (size_t)(row0 + m) * NSHP + 32 * nt : nullptr;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const int n = 32 * nt + k;                 // (compile-time: the colour and basis indices below are constants)
+                float v = 0.f;
+                if (n < NSH) {
+                    v = ssh[m * 33 + k] + prm[L.pBc2 + n];
+                    pre[n / NB] += b[n % NB] * v;
+                }
+                if (SAVE) dst[k] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (mine) {
+        float sigma = prm[L.pBs2];
+#pragma unroll
+        for (int w = 0; w < WN; ++w) sigma += ssig[w * MT + m];
+        f32x4 o;
+        o[0] = sigma;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[1 + c] = 1.0f / (1.0f + expf(-pre[c]));
+        *reinterpret_cast<f32x4*>(a.out + (size_t)saddr[m] * 4) = o;
+    }
+}
+
 template <int WIDTH, bool SAVE>
 __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) void mlp_fwd_kernel(McnMlpFwdArgs a) {
     using G = McnGeom<WIDTH>;
@@ -209,6 +269,14 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             SAVE ? a.act_save + (size_t)(L.depth + 1) * a.act_stride : nullptr,
             SAVE ? a.mask_save + (size_t)(L.depth + 1) * (a.act_stride / 32) : nullptr, unused, mrow0, ncol0, row0, total, lane);
         __syncthreads();
+    }
+    if (L.sh_deg != 2) {          // (block-uniform) general SH degree: templated on the degree so that every index is a constant
+        switch (L.sh_deg) {
+            case 0: mcn_sh_head_general<WIDTH, SAVE, 0>(a, X, ssh, ssig, sdir, saddr, pk, prm, row0, total, tid, lane, wave); break;
+            case 1: mcn_sh_head_general<WIDTH, SAVE, 1>(a, X, ssh, ssig, sdir, saddr, pk, prm, row0, total, tid, lane, wave); break;
+            default: mcn_sh_head_general<WIDTH, SAVE, 3>(a, X, ssh, ssig, sdir, saddr, pk, prm, row0, total, tid, lane, wave); break;
+        }
+        return;
     }
     // ---- SH output layer (27 -> 32 padded outputs): one 32-row m-tile per wave
     for (int mt = wave; mt < MT / 32; mt += WAVES) {

@@ -84,7 +84,7 @@ static void build_pack_table(const McnLayout& L, PackTable& t) {
     }
     add(L.pWs1, W, 0, W, W, W, W, L.fS1, L.bS1);
     add(L.pWc1, W, 0, W, W, W, W, L.fC1, L.bC1);
-    add(L.pWc2, W, 0, MCN_NSH, W, MCN_NSHP, W, L.fC2, L.bC2);
+    add(L.pWc2, W, 0, L.nsh, W, L.nshp, W, L.fC2, L.bC2);
     t.nseg = ns;
     t.total4 = first4;
 }

@@ -67,9 +67,9 @@ class NeRF_Model(nn.Module):
         self.precision = sys_param.get("precision", "f32")
         if self.precision not in ops.PRECISIONS:
             raise ValueError(f"precision must be one of {ops.PRECISIONS}")
-        if self.precision != "f32" and (self.nerf_coarse.net.multi_skip or self.nerf_fine.net.multi_skip):
-            raise ValueError("a net with more than one skip layer runs in precision 'f32' only (the register-chain kernels of "
-                             f"'{self.precision}' take one skip layer)")
+        if self.precision != "f32" and (self.nerf_coarse.net.fp32_only or self.nerf_fine.net.fp32_only):
+            raise ValueError("a net with more than one skip layer or an SH degree other than 2 runs in precision 'f32' only (the "
+                             f"register-chain kernels of '{self.precision}' take one skip layer and MLP_deg = 2)")
         self.settings = RenderSettings(self.samples_c, self.sample_scale, float(self.weight_thresh),
                                        float(self.sigma_default), bool(self.white_back), precision=self.precision)
         self.last_selection = None

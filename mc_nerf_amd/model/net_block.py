@@ -124,15 +124,17 @@ class CorseFine_NeRF(nn.Module):
         super().__init__()
         self.in_channels_xyz = 3 * (2 * sys_params["emb_freqs_xyz"] + 1)
         self.deg = sys_params["MLP_deg"]
-        if self.deg != 2 or self.in_channels_xyz != 63:
-            raise ValueError("the HIP kernels are built for MLP_deg = 2 and 63 encoded channels")
+        if self.in_channels_xyz != 63:
+            raise ValueError("the HIP kernels are built for 63 encoded channels (emb_freqs_xyz = 10)")
+        if not 0 <= self.deg <= 3:
+            raise ValueError("SH degrees 0 .. 3 are built (MLP_deg)")
         key = "coarse" if type == "coarse" else "fine"
         self.depth = sys_params[f"{key}_MLP_depth"]
         self.width = sys_params[f"{key}_MLP_width"]
         self.skips = list(sys_params[f"{key}_MLP_skip"])
-        # any `skips` list (reference :45, 55-58); more than one skip layer runs on the exact-fp32 kernel family only
+        # any `skips` list (reference :45, 55-58) and SH degree 0 .. 3 (:43, 75-76); more than one skip layer or a degree other than 2 run on the exact-fp32 kernel family only
         # (NeRF_Model refuses the register-chain precision modes for such a net)
-        self.net = ops.Net(self.depth, self.width, ops.skip_code(self.skips, self.depth))
+        self.net = ops.Net(self.depth, self.width, ops.skip_code(self.skips, self.depth, self.deg))
         for i in range(self.depth):
             fan_in = self.net.in_features(i)
             setattr(self, f"xyz_encoding_{i+1}", nn.Sequential(nn.Linear(fan_in, self.width), nn.ReLU(True)))

@@ -19,15 +19,18 @@ Tensor = torch.Tensor
 SKIP_MASK = 256          # MCN_SKIP_MASK: skip >= 256 = (bit mask of skip layers) << 8 (include/mcnerf.h)
 
 
-def skip_code(skips, depth: int) -> int:
-    """The reference's `skips` list (model/net_block.py:45) -> the C ABI's `skip` argument: -1 (none), the layer index (one),
-    or a bit mask << 8 (several: exact-fp32 kernels only)."""
+def skip_code(skips, depth: int, deg: int = 2) -> int:
+    """The reference's `skips` list and `MLP_deg` (model/net_block.py:43-45) -> the C ABI's `skip` argument: -1 (no skip layer),
+    the layer index (one), or the mask form -- (bit mask of skip layers | 1) << 8, with 0x80 | deg << 4 in the low byte when the SH
+    degree is not 2 (several skip layers or another degree: exact-fp32 kernels only)."""
     ks = sorted({int(k) for k in skips if 0 < int(k) < depth})
-    if not ks:
+    if not 0 <= deg <= 3:
+        raise ValueError("SH degrees 0 .. 3 are built")
+    if deg == 2 and not ks:
         return -1
-    if len(ks) == 1:
+    if deg == 2 and len(ks) == 1:
         return ks[0]
-    return sum(1 << k for k in ks) << 8
+    return ((sum(1 << k for k in ks) | 1) << 8) | ((0x80 | (deg << 4)) if deg != 2 else 0)
 
 
 @dataclass(frozen=True)
@@ -45,12 +48,29 @@ class Net:
     @property
     def skips(self):
         if self.skip >= SKIP_MASK:
-            return [l for l in range(self.depth) if (self.skip >> 8) >> l & 1]
+            return [l for l in range(1, self.depth) if (self.skip >> 8) >> l & 1]
         return [self.skip] if 0 < self.skip < self.depth else []
 
     @property
     def multi_skip(self) -> bool:
         return len(self.skips) > 1
+
+    @property
+    def deg(self) -> int:
+        return (self.skip >> 4) & 7 if self.skip >= SKIP_MASK and self.skip & 0x80 else 2
+
+    @property
+    def n_sh(self) -> int:
+        return 3 * (self.deg + 1) ** 2
+
+    @property
+    def n_shp(self) -> int:
+        return 32 if self.n_sh < 32 else 64
+
+    @property
+    def fp32_only(self) -> bool:
+        """Topologies only the exact-fp32 kernel family takes (the register-chain modes: one skip layer, SH degree 2)."""
+        return self.multi_skip or self.deg != 2
 
     def in_features(self, i: int) -> int:
         if i == 0:
@@ -63,7 +83,7 @@ class Net:
         for i in range(self.depth):
             s += [(self.width, self.in_features(i)), (self.width,)]
         s += [(self.width, self.width), (self.width,), (1, self.width), (1,),
-              (self.width, self.width), (self.width,), (27, self.width), (27,)]
+              (self.width, self.width), (self.width,), (self.n_sh, self.width), (self.n_sh,)]
         return s
 
     def names(self):
@@ -227,7 +247,7 @@ def alloc_save(net: Net, capacity: int, device, precision: str = "f32") -> MlpSa
     return MlpSave(capacity,
                    torch.empty((net.depth + 2) * capacity * net.width, dtype=torch.float32, device=device),
                    torch.empty(capacity * 64, dtype=torch.float32, device=device),
-                   torch.empty(capacity * 32, dtype=torch.float32, device=device),
+                   torch.empty(capacity * net.n_shp, dtype=torch.float32, device=device),
                    torch.empty((net.depth + 2) * capacity * (net.width // 32), dtype=torch.int32, device=device))
 
 

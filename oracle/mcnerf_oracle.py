@@ -113,6 +113,31 @@ def eval_sh_deg2(sh: Tensor, dirs: Tensor) -> Tensor:
     return (sh * sh_basis_deg2(dirs).unsqueeze(-2)).sum(-1)
 
 
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
+         -0.4570457994644658, 1.445305721320277, -0.5900435899266435)
+
+
+def eval_sh(deg: int, sh: Tensor, dirs: Tensor) -> Tensor:
+    """eval_sh for degrees 0 .. 3 (model/net_utils.py:103-179), term by term in the reference's order:
+    sh [M,3,(deg+1)^2], dirs [M,3] -> [M,3]."""
+    assert 0 <= deg <= 3 and sh.shape[-1] == (deg + 1) ** 2
+    result = SH_C0 * sh[..., 0]
+    if deg > 0:
+        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+        result = (result - SH_C1 * y * sh[..., 1] + SH_C1 * z * sh[..., 2] - SH_C1 * x * sh[..., 3])
+        if deg > 1:
+            xx, yy, zz = x * x, y * y, z * z
+            xy, yz, xz = x * y, y * z, x * z
+            result = (result + SH_C2[0] * xy * sh[..., 4] + SH_C2[1] * yz * sh[..., 5] + SH_C2[2] * (2.0 * zz - xx - yy) * sh[..., 6] +
+                      SH_C2[3] * xz * sh[..., 7] + SH_C2[4] * (xx - yy) * sh[..., 8])
+            if deg > 2:
+                result = (result + SH_C3[0] * y * (3 * xx - yy) * sh[..., 9] + SH_C3[1] * xy * z * sh[..., 10] +
+                          SH_C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12] +
+                          SH_C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + SH_C3[5] * z * (xx - yy) * sh[..., 14] +
+                          SH_C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return result
+
+
 # --------------------------------------------------------------------------- MLP
 def mlp_forward(p: Dict[str, Tensor], net: NetCfg, x_enc: Tensor, dirs: Tensor,
                 return_hidden: bool = False):
@@ -133,7 +158,8 @@ def mlp_forward(p: Dict[str, Tensor], net: NetCfg, x_enc: Tensor, dirs: Tensor,
     sigma = F.linear(hs, p["sigma.2.weight"], p["sigma.2.bias"])
     hc = F.relu(F.linear(h, p["sh.0.weight"], p["sh.0.bias"]))
     sh = F.linear(hc, p["sh.2.weight"], p["sh.2.bias"])
-    rgb = torch.sigmoid(eval_sh_deg2(sh.reshape(-1, 3, 9), dirs))
+    nb = sh.shape[-1] // 3                                  # (deg + 1)^2, from the sh.2 layer's width (MLP_deg, model/net_block.py:43)
+    rgb = torch.sigmoid(eval_sh_deg2(sh.reshape(-1, 3, 9), dirs) if nb == 9 else eval_sh(int(round(nb ** 0.5)) - 1, sh.reshape(-1, 3, nb), dirs))
     out = torch.cat([sigma, rgb], dim=-1)
     if return_hidden:
         return out, hidden + [hs, hc], sh

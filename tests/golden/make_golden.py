@@ -110,7 +110,8 @@ def npz(name, **arrs):
 
 
 def load_nets(model: NeRF_Model, cfg: O.RenderCfg, seed_c, seed_f, sigma_bias_shift=0.0):
-    pc, pf = O.init_params(cfg.coarse, seed_c), O.init_params(cfg.fine, seed_f)
+    n_sh = 3 * (cfg.deg + 1) ** 2
+    pc, pf = O.init_params(cfg.coarse, seed_c, n_sh=n_sh), O.init_params(cfg.fine, seed_f, n_sh=n_sh)
     if sigma_bias_shift:
         pc["sigma.2.bias"] = pc["sigma.2.bias"] + sigma_bias_shift
         pf["sigma.2.bias"] = pf["sigma.2.bias"] + sigma_bias_shift
@@ -195,7 +196,8 @@ def g7_train(tag, cfg: O.RenderCfg, n, seed, step_r, sigma_shift=0.0, only_coars
                 cfg=np.array([cfg.samples, cfg.scale, cfg.coarse.depth, cfg.coarse.width, cfg.coarse.skips[0],
                               cfg.fine.depth, cfg.fine.width, cfg.fine.skips[0], int(cfg.barf_mode)]),
                 barf=np.array([cfg.barf_start, cfg.barf_end]),
-                skips_c=np.array(cfg.coarse.skips), skips_f=np.array(cfg.fine.skips))      # (the whole `skips` lists; `cfg` holds the first entries)
+                skips_c=np.array(cfg.coarse.skips), skips_f=np.array(cfg.fine.skips),      # (the whole `skips` lists; `cfg` holds the first entries)
+                deg=cfg.deg)
     if only_coarse:
         arrs["depth_c"] = depth_c
     else:
@@ -389,13 +391,25 @@ def g7_multi_skip():
     g7_train("g7_train_s32x2_multiskip", O.RenderCfg(samples=32, scale=2, coarse=O.NetCfg(4, 32, (1, 3)), fine=O.NetCfg(8, 64, (2, 4, 6))), 80, 76, 1.0)
 
 
+def g7_sh_degrees():
+    """General topology: `MLP_deg` 0, 1 and 3 (model/net_block.py:43, 75-76; eval_sh, model/net_utils.py:103-179): 3, 12 and 48
+    sh.2 outputs; one small train render + backward of the actual reference each."""
+    small = dict(coarse=O.NetCfg(4, 32, (2,)), fine=O.NetCfg(8, 64, (4,)))
+    for deg in (0, 1, 3):
+        g7_train(f"g7_train_s32x2_deg{deg}", O.RenderCfg(samples=32, scale=2, deg=deg, **small), 72, 77 + deg, 1.0)
+
+
 def main():
     torch.set_num_threads(4)
+    if "--only-sh-degrees" in sys.argv:
+        return g7_sh_degrees()
     if "--only-full-size" in sys.argv:
         return g7_full_size()
     if "--only-multi-skip" in sys.argv:
         return g7_multi_skip()
     g7_multi_skip()
+    g7_sh_degrees()
+    g7_sh_degrees()
     g7_full_size()
     g11_mc_model_step()
     g11_mc_model_step("CAM_PARAM_EPOCH", "g11b_mc_model_cam_param", extr_shift=0.7)

@@ -82,6 +82,36 @@ def test_render_rays_train_matches_reference(gpu_device, name, precision):
     assert checked == len(list(m.nerf_coarse.parameters())) + len(list(m.nerf_fine.parameters()))
 
 
+def _oracle_reorder_noise(g, cfg):
+    """Per parameter tensor ("c.<name>" / "f.<name>"): what the ORACLE's own gradient does on this fixture when the hidden units
+    of every layer are enumerated in another order (oracle.permute_hidden_units), relative to the tensor's largest gradient (for a
+    bias also its layer's weight gradient) -- the floor under any fp32 comparison of sums with cancellation."""
+    def run(permute):
+        pc, pf = nets_from_golden(g, cfg)
+        undo = (lambda x: x, lambda x: x)
+        if permute:
+            (pc, uc), (pf, uf) = O.permute_hidden_units(pc, cfg.coarse, 1), O.permute_hidden_units(pf, cfg.fine, 2)
+            undo = (uc, uf)
+        for p in list(pc.values()) + list(pf.values()):
+            p.requires_grad_(True)
+        r = O.render_rays_train(pc, pf, cfg, t(g["rays_d"]), t(g["rays_o"]), float(g["step_r"]), t(g["jitter"]), t(g["eps_c"]), t(g["eps_sel"]), t(g["eps_f"]),
+                                cap_perm=t(g["cap_perm"]) if "cap_perm" in g else None)
+        O.rgb_loss(r["rgb_c"], r["rgb_f"], t(g["gt"])).backward()
+        out = {}
+        for tag, d_, un in (("c", pc, undo[0]), ("f", pf, undo[1])):
+            for k_, v in un({k_: p.grad for k_, p in d_.items()}).items():
+                out[f"{tag}.{k_}"] = v
+        return out
+    a, b = run(False), run(True)
+    noise = {}
+    for k_ in a:
+        scale = float(a[k_].abs().max())
+        if k_.endswith(".bias"):
+            scale = max(scale, float(a[k_[:-4] + "weight"].abs().max()))
+        noise[k_] = float((a[k_] - b[k_]).abs().max()) / max(scale, 1e-30)
+    return noise
+
+
 def test_multi_skip_topology_matches_reference(gpu_device):
     """General topology (reference: `skips` is a list, model/net_block.py:45, 55-58, 71): coarse 4 x 32 with the encoding
     re-concatenated at layers 1 and 3, fine 8 x 64 at layers 2, 4 and 6 -- train render + backward against the golden captured
@@ -126,6 +156,57 @@ def test_multi_skip_topology_matches_reference(gpu_device):
     for precision in ("f16x3", "f16", "bf16"):
         with pytest.raises(ValueError, match="more than one skip layer"):
             NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision=precision))
+
+
+@pytest.mark.parametrize("deg", [0, 1, 3])
+def test_sh_degree_topology_matches_reference(gpu_device, deg):
+    """General topology: `MLP_deg` 0, 1, 3 (model/net_block.py:43, 75-76; eval_sh up to degree 3, model/net_utils.py:103-179): 3, 12, 48
+    sh.2 outputs.  Train render + backward against the golden captured from the actual reference on the exact-fp32 kernel family
+    (templated per degree; degree 3 runs sh.2 as two 32-row tiles), incl. the view-direction gradient through the basis
+    derivatives; the register-chain precision modes refuse the net."""
+    from mc_nerf_amd.model import MC_NeRF_Loss, NeRF_Model
+    g = load_golden(f"g7_train_s32x2_deg{deg}")
+    dev = gpu_device
+    m, cfg, pc, pf = build_model(g, dev, precision="f32")
+    n_sh = 3 * (deg + 1) ** 2
+    assert cfg.deg == deg and m.nerf_fine.sh[2].weight.shape == (n_sh, 64) and m.nerf_fine.net.deg == deg
+    d = t(g["rays_d"]).to(dev).requires_grad_(True)
+    o = t(g["rays_o"]).to(dev).requires_grad_(True)
+    rgb_c, rgb_f = m.render_rays_train(d, o, 0, float(g["step_r"]), jitter=t(g["jitter"]).to(dev), eps_c=t(g["eps_c"]).to(dev),
+                                       eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
+    assert err(rgb_c, g["rgb_c"]) < TOL and err(rgb_f, g["rgb_f"]) < TOL
+    loss = MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([rgb_c, rgb_f, t(g["gt"]).to(dev)])
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    loss.backward()
+    e_d = err(d.grad, g["d_rays_d"]) / float(np.abs(g["d_rays_d"]).max())
+    e_o = err(o.grad, g["d_rays_o"]) / float(np.abs(g["d_rays_o"]).max())
+    assert e_d < 1e-4 and e_o < 1e-4, (e_d, e_o)
+    worst = 0.0
+    noise = _oracle_reorder_noise(g, cfg)
+    for tag, net in (("c", m.nerf_coarse), ("f", m.nerf_fine)):
+        for k_, p in net.named_parameters():
+            ref = g[f"g{tag}.{k_}"] if f"g{tag}.{k_}" in g else g[f"gsamp{tag}.{k_}"]
+            got = p.grad if f"g{tag}.{k_}" in g else p.grad.reshape(-1)[::97]
+            scale = float(np.abs(ref).max())
+            if k_.endswith(".bias"):             # (a bias gradient is a plain sum over the samples -- sigma.2's a single number: its
+                wk = k_[:-4] + "weight"          #  cancellation is measured against the layer's weight gradient as well)
+                wref = g[f"g{tag}.{wk}"] if f"g{tag}.{wk}" in g else g[f"gsamp{tag}.{wk}"]
+                scale = max(scale, float(np.abs(wref).max()))
+            e = err(got, ref) / max(scale, 1e-30)
+            worst = max(worst, e)
+            # 3e-4 of the tensor's scale (measured <= 1.5e-4: sigma.0 of the fine net at degree 3, a tensor the SH head does not
+            # touch -- one ReLU decision), or 8 x what the reference arithmetic itself does to this tensor under a re-ordering of the
+            # hidden units (degree 0: the coarse sigma gradients nearly cancel -- |d b_sigma2| = 6e-7 -- and that noise alone is 1.1e-4)
+            assert e < max(3e-4, 8.0 * noise[f"{tag}.{k_}"]), (tag, k_, e, noise[f"{tag}.{k_}"])
+    print(f"MLP_deg = {deg} ({n_sh} sh.2 outputs) vs the reference's golden: rgb {max(err(rgb_c, g['rgb_c']), err(rgb_f, g['rgb_f'])):.1e}, "
+          f"d_rays_d {e_d:.1e}, worst parameter gradient {worst:.1e} of its tensor's max")
+    with torch.no_grad():
+        r = O.render_rays_test(pc, pf, cfg, t(g["rays_d"]), t(g["rays_o"]), t(g["eps_c"]), t(g["eps_sel"]), t(g["eps_f"]))
+        rgb, depth, opacity = m.render_rays_test(t(g["rays_d"]).to(dev), t(g["rays_o"]).to(dev), m.nerf_coarse, m.nerf_fine,
+                                                 eps_c=t(g["eps_c"]).to(dev), eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
+    assert float((rgb.cpu() - r["rgb"]).abs().max()) < TOL
+    with pytest.raises(ValueError, match="SH degree other than 2"):
+        NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision="f16x3"))
 
 
 # per mode: (rgb abs, worst per-tensor gradient error as a multiple of the reference's own worst reorder noise, median over the
