@@ -75,18 +75,20 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
         const int pi = wave + MCN16_WAVES * i;
         const int which = pi < KSN ? 0 : (pi < KSN + KSK1 ? 1 : 2);
         const int s = which == 0 ? pi : (which == 1 ? pi - KSN : pi - KSN - KSK1);
-        const int m_src = mm ^ (4 * (2 * (s & 1) + hh));
+        // (every piece of this wave has (s & 1) = (wave & 1): KSN and KSK1 are even -- so the lane's byte offset inside a fragment is
+        //  one value, `voff`, and a piece is a wave-uniform base: SADDR-form LDS-DMA, scalar registers instead of a lane pointer each)
         const char* base = which == 0 ? sg.dY + ((size_t)t0 * KSN + s) * 1024
                          : which == 1 ? sg.X + ((size_t)t0 * KSK1 + s) * 1024
                                       : sg.X2 + ((size_t)t0 * KSK2 + s) * 1024;
-        src[i] = base + (hh * 32 + m_src) * 16;
+        src[i] = base;
     }
+    const unsigned voff = (unsigned)(hh * 32 + (mm ^ (4 * (2 * (wave & 1) + hh)))) * 16;
     const int np = (P % MCN16_WAVES == 0 || wave < P % MCN16_WAVES) ? PW : PW - 1;      // wave-uniform
     auto fill = [&](int stage) {
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int pi = wave + MCN16_WAVES * i;
-            if (i < np) mcn16_dma16_nt(src[i], lds_base + stage * STAGE + pi * 1024);     // read once: non-temporal (6.5 -> 6.06 ms per fine-net call)
+            if (i < np) mcn16_dma16_nt_s(src[i], voff, lds_base + stage * STAGE + pi * 1024);     // read once: non-temporal (6.5 -> 6.06 ms per fine-net call)
             src[i] += (size_t)(pi < KSN ? KSN : (pi < KSN + KSK1 ? KSK1 : KSK2)) * 1024;
         }
     };
