@@ -19,9 +19,11 @@
  *     layer, skip >= 256 = the mask form: bits 8 + l set for every such layer l (bit 8 itself, layer 0,
  *     is ignored and may serve as the marker of the form) -- the reference's `skips` is a list
  *     (model/net_block.py:45, 55-58) -- and, when bit 7 is set, the SH degree of the colour head in
- *     bits 4..6 (`MLP_deg` 0 .. 3, model/net_block.py:43, 75-76; 3 (deg + 1)^2 sh.2 outputs; default 2).
- *     The exact-fp32 entry points take any mask and degree, the `_16` entry points (f16 / bf16 / f16x3
- *     register chains) at most one skip layer and degree 2;
+ *     bits 4..6 (`MLP_deg` 0 .. 3, model/net_block.py:43, 75-76; 3 (deg + 1)^2 sh.2 outputs; default 2), and in
+ *     bits 0..3 the number of encoding frequencies + 1 (`emb_freqs_xyz` 0 .. 10, model/net_block.py:11-18:
+ *     3 + 6 F encoded channels; 0 = the default 10).  The exact-fp32 entry points take any mask, degree and
+ *     frequency count, the `_16` entry points (f16 / bf16 / f16x3 register chains) at most one skip layer,
+ *     degree 2 and 10 frequencies;
  *   - parameters of one net live in ONE flat fp32 buffer in the reference's state-dict order
  *     (xyz_encoding_{1..depth}.0.{weight,bias}, sigma.0.*, sigma.2.*, sh.0.*, sh.2.*), Linear weights
  *     [out][in] row-major; gradients use the same layout.
@@ -85,9 +87,9 @@ int mcnerf_mlp_fwd(int depth, int width, int skip, const float* params, const fl
 
 /* The two modules of model/net_block.py as stand-alone forward calls (exact fp32 MFMA; the render path never materialises
  * these tensors):
- *   mcnerf_encode   = SinCosEmbedding.forward (:20-35): x [n,3], barf_w [10] -> out [n,63];
+ *   mcnerf_encode   = SinCosEmbedding.forward (:20-35): x [n,3], barf_w [n_freqs] -> out [n, 3 + 6 n_freqs] (`emb_freqs_xyz`; 10 -> 63);
  *   mcnerf_mlp_apply = CorseFine_NeRF.forward (:67-78): x_enc [n,63], dirs [n,3] -> out [n,4] = (sigma_raw, r, g, b). */
-int mcnerf_encode(const float* x, const float* barf_w, int n, float* out, void* stream);
+int mcnerf_encode(const float* x, const float* barf_w, int n, int n_freqs, float* out, void* stream);
 
 /* Stream-ordered upload of up to 16 host floats WITHOUT a host-device copy: the values travel as kernel arguments and a
  * one-wave kernel stores them to `dst` (device).  For the per-step host scalars of the train step (the ten BARF weights of
@@ -99,12 +101,12 @@ int mcnerf_mlp_apply(int depth, int width, int skip, const float* params, const 
 
 /* The same two modules DIFFERENTIATED (both are autograd-differentiable in the reference; the host classes wrap these in
  * torch.autograd.Functions, model/net_block.py):
- *   mcnerf_encode_bwd:     d_out [n,63] -> d_x [n,3] (written);
+ *   mcnerf_encode_bwd:     d_out [n, 3 + 6 n_freqs] -> d_x [n,3] (written);
  *   mcnerf_mlp_apply_save: mcnerf_mlp_apply that also fills the exact-fp32 workspaces of mcnerf_mlp_fwd (capacity >= n);
  *   mcnerf_mlp_apply_bwd:  d_out [n,4] -> d_x_enc [n,63] (written), d_dirs [n,3] (ACCUMULATED: zero it first; the SH view-direction
  *                          term) and dy_save / dsh_save, from which mcnerf_mlp_dw reduces the parameter gradients as for the
  *                          render path.  `zero` is a device float holding 0 (the sample depth of the degenerate one-sample ray). */
-int mcnerf_encode_bwd(const float* x, const float* barf_w, int n, const float* d_out, float* d_x, void* stream);
+int mcnerf_encode_bwd(const float* x, const float* barf_w, int n, int n_freqs, const float* d_out, float* d_x, void* stream);
 int mcnerf_mlp_apply_save(int depth, int width, int skip, const float* params, const float* packed, const float* x_enc,
                           const float* dirs, int n, float* out, float* act_save, long long capacity, float* enc_save,
                           float* sh_save, uint32_t* mask_save, void* stream);

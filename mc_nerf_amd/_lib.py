@@ -33,13 +33,13 @@ SIGNATURES = {
     "mcnerf_raygen_fwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "mcnerf_raygen_bwd": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "mcnerf_mlp_fwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P]),
-    "mcnerf_encode": (_I, [_P, _P, _I, _P, _P]),
+    "mcnerf_encode": (_I, [_P, _P, _I, _I, _P, _P]),
     "mcnerf_upload_f32": (_I, [_P, _P, _I, _P]),
     "mcnerf_train_loss": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "mcnerf_scale3": (_I, [_P, _I, _P, _I, _P, _I, _P, _P]),
     "mcnerf_sample_perm": (_I, [_P, ctypes.c_longlong, _I, _P, _P]),
     "mcnerf_mlp_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
-    "mcnerf_encode_bwd": (_I, [_P, _P, _I, _P, _P, _P]),
+    "mcnerf_encode_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "mcnerf_sync_finish": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "mcnerf_mlp_apply_save": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _L, _P, _P, _P, _P]),
     "mcnerf_mlp_apply_bwd": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P]),

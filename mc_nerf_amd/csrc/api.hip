@@ -27,11 +27,11 @@ static bool net_ok(int depth, int width, int skip) {
     if (!(depth >= 1 && depth <= MCN_MAXD && (width == 32 || width == 64 || width == 128 || width == 256))) return false;
     if (skip < -1) return false;
     if (skip >= MCN_SKIP_MASK && ((skip >> 8) >> depth) != 0) return false;          // -1, a layer index, or a mask of layers < depth
-    return mcn_topo_deg(skip) <= MCN_MAXDEG;
+    return mcn_topo_deg(skip) <= MCN_MAXDEG && mcn_topo_nfreq(skip) <= MCN_NFREQ;
 }
-// the register-chain families (f16 / bf16 / f16x3) take at most one skip layer and SH degree 2
+// the register-chain families (f16 / bf16 / f16x3) take at most one skip layer, SH degree 2 and 10 encoding frequencies
 static bool net16_ok(int depth, int width, int skip) {
-    return net_ok(depth, width, skip) && mcn_single_skip(mcn_skip_mask(depth, skip)) != -2 && mcn_topo_deg(skip) == 2;
+    return net_ok(depth, width, skip) && mcn_single_skip(mcn_skip_mask(depth, skip)) != -2 && mcn_topo_deg(skip) == 2 && mcn_topo_nfreq(skip) == MCN_NFREQ;
 }
 #define REQ(cond, name) do { if (!(cond)) return fail(name, "invalid argument: " #cond); } while (0)
 
@@ -122,9 +122,9 @@ int mcnerf_upload_f32(float* dst, const float* host_vals, int n, void* stream) {
     return check("mcnerf_upload_f32", mcn_launch_upload_f32(dst, host_vals, n, (hipStream_t)stream));
 }
 
-int mcnerf_encode(const float* x, const float* barf_w, int n, float* out, void* stream) {
-    REQ(x && barf_w && out && n >= 0, "mcnerf_encode");
-    return check("mcnerf_encode", mcn_launch_encode(x, barf_w, n, out, (hipStream_t)stream));
+int mcnerf_encode(const float* x, const float* barf_w, int n, int n_freqs, float* out, void* stream) {
+    REQ(x && barf_w && out && n >= 0 && n_freqs >= 0 && n_freqs <= 16, "mcnerf_encode");
+    return check("mcnerf_encode", mcn_launch_encode(x, barf_w, n, n_freqs, out, (hipStream_t)stream));
 }
 int mcnerf_mlp_apply(int depth, int width, int skip, const float* params, const float* packed, const float* x_enc,
                      const float* dirs, int n, float* out, void* stream) {
@@ -138,9 +138,9 @@ int mcnerf_mlp_apply(int depth, int width, int skip, const float* params, const 
     return check("mcnerf_mlp_apply", mcn_launch_mlp_fwd(a, (hipStream_t)stream));
 }
 
-int mcnerf_encode_bwd(const float* x, const float* barf_w, int n, const float* d_out, float* d_x, void* stream) {
-    REQ(x && barf_w && d_out && d_x && n >= 0, "mcnerf_encode_bwd");
-    return check("mcnerf_encode_bwd", mcn_launch_encode_bwd(x, barf_w, n, d_out, d_x, (hipStream_t)stream));
+int mcnerf_encode_bwd(const float* x, const float* barf_w, int n, int n_freqs, const float* d_out, float* d_x, void* stream) {
+    REQ(x && barf_w && d_out && d_x && n >= 0 && n_freqs >= 0 && n_freqs <= 16, "mcnerf_encode_bwd");
+    return check("mcnerf_encode_bwd", mcn_launch_encode_bwd(x, barf_w, n, n_freqs, d_out, d_x, (hipStream_t)stream));
 }
 // CorseFine_NeRF.forward with the operands of its backward saved (exact-fp32 workspaces, as mcnerf_mlp_fwd's), and that backward
 int mcnerf_mlp_apply_save(int depth, int width, int skip, const float* params, const float* packed, const float* x_enc,

@@ -37,6 +37,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MCN_SKIP_MASK 256
 #define MCN_TOPO_HAS_DEG 0x80
 static inline int mcn_topo_deg(int skip) { return (skip >= MCN_SKIP_MASK && (skip & MCN_TOPO_HAS_DEG)) ? ((skip >> 4) & 7) : 2; }
+// ... and in bits 0..3 the number of encoding frequencies + 1 (`emb_freqs_xyz`, model/net_block.py:11-18: 3 + 6 F input channels;
+// 0 = the default 10).  F <= 10 (the 64-column encoded-input tiles of every kernel); F != 10: exact-fp32 family only.
+static inline int mcn_topo_nfreq(int skip) { return (skip >= MCN_SKIP_MASK && (skip & 15)) ? (skip & 15) - 1 : MCN_NFREQ; }
 static inline unsigned mcn_skip_mask(int depth, int skip) {
     if (skip >= MCN_SKIP_MASK) return ((unsigned)skip >> 8) & ((1u << depth) - 1u) & ~1u;      // (layer 0 takes the encoding alone)
     return (skip > 0 && skip < depth) ? (1u << skip) : 0u;
@@ -54,6 +57,7 @@ struct McnLayout {
     int depth, width, skip;      // skip: the single skip layer, -1 none, -2 several (skip_mask has them all)
     unsigned skip_mask;
     int sh_deg, nb, nsh, nshp;   // SH degree, (deg + 1)^2 basis functions, 3 nb outputs of sh.2, padded to 32 / 64 (+ 1 spare column for d sigma)
+    int nfreq, nenc;             // encoding frequencies F and 3 + 6 F encoded channels (<= MCN_ENC; padded to MCN_ENCP columns everywhere)
     // flat parameter buffer (reference order)
     int pW[MCN_MAXD], pB[MCN_MAXD];
     int pWs1, pBs1, pWs2, pBs2, pWc1, pBc1, pWc2, pBc2;
@@ -70,12 +74,13 @@ struct McnLayout {
 };
 
 static inline int mcn_in_features(int depth, int width, int skip, int i) {       // (`skip` in the ABI's encoding)
-    if (i == 0) return MCN_ENC;
-    return ((mcn_skip_mask(depth, skip) >> i) & 1u) ? width + MCN_ENC : width;
+    const int nenc = 3 + 6 * mcn_topo_nfreq(skip);
+    if (i == 0) return nenc;
+    return ((mcn_skip_mask(depth, skip) >> i) & 1u) ? width + nenc : width;
 }
 
-static inline int mcn_layer_in(unsigned skip_mask, int width, int i) {              // input features of trunk layer i
-    return i == 0 ? MCN_ENC : (((skip_mask >> i) & 1u) ? width + MCN_ENC : width);
+static inline int mcn_layer_in(const McnLayout& L, int i) {                         // input features of trunk layer i
+    return i == 0 ? L.nenc : (((L.skip_mask >> i) & 1u) ? L.width + L.nenc : L.width);
 }
 
 static inline McnLayout mcn_make_layout(int depth, int width, int skip) {
@@ -87,6 +92,8 @@ static inline McnLayout mcn_make_layout(int depth, int width, int skip) {
     L.nb = (L.sh_deg + 1) * (L.sh_deg + 1);
     L.nsh = 3 * L.nb;
     L.nshp = L.nsh < 32 ? 32 : 64;
+    L.nfreq = mcn_topo_nfreq(skip);
+    L.nenc = 3 + 6 * L.nfreq;
     int o = 0;
     // every tensor starts on a 16-byte boundary so that float4 loads of biases / weight rows are aligned
     auto al = [&o]() { o = (o + 3) & ~3; return o; };

@@ -23,8 +23,8 @@ struct McnMlpFwdArgs {
     unsigned int* mask_save;  // [(depth+2)][capacity][width/32] ReLU masks (bit c of word g = column 32g+c is > 0)
     const float* enc_in = nullptr;   // fp32 kernel only: caller-supplied encodings [rows][63] instead of the fused positional encoding
 };
-hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, float* out, hipStream_t st);
-hipError_t mcn_launch_encode_bwd(const float* x, const float* barf_w, int n, const float* d_out, float* d_x, hipStream_t st);
+hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, int n_freqs, float* out, hipStream_t st);
+hipError_t mcn_launch_encode_bwd(const float* x, const float* barf_w, int n, int n_freqs, const float* d_out, float* d_x, hipStream_t st);
 hipError_t mcn_launch_sample_perm(long long* out, long long n, int batch, const unsigned* seed, hipStream_t st);
 #define MCN_LOSS_BLOCKS 128          // (include/mcnerf.h: MCNERF_TRAIN_LOSS_OUT = 4 + MCN_LOSS_BLOCKS floats of `out`)
 hipError_t mcn_launch_train_loss(const float* pd, const float* ptg, int np, int H, int W, int normalise, const float* rgb_c, const float* rgb_f,

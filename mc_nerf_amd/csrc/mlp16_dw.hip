@@ -300,7 +300,7 @@ hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
     if (D + 5 > DW16_MAXSEG) return hipErrorInvalidValue;
     const bool merged = (W == 256 || W == 128);       // (Dw16SkipMerged)
     for (int l = 0; l < D; ++l) {
-        const int ldw = mcn_layer_in(L.skip_mask, W, l);
+        const int ldw = mcn_layer_in(L, l);
         float* dWl = a.grads + L.pW[l];
         float* dbl = a.grads + L.pB[l];
         if (l == 0)                       // encoded-input columns only

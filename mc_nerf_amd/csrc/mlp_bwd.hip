@@ -280,14 +280,16 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
     }
     __syncthreads();
     if (a.d_enc_out) {     // caller-supplied encodings (model/net_block.py:67-78 differentiated with respect to its input x)
-        for (int it = tid; it < MT * MCN_ENC; it += NT) {
-            const int m = it / MCN_ENC, ch = it - m * MCN_ENC;
-            if (row0 + m < total) a.d_enc_out[(size_t)(row0 + m) * MCN_ENC + ch] = X[mcn_swz(m, ch, XW)];
+        const int nenc = L.nenc;
+        for (int it = tid; it < MT * nenc; it += NT) {
+            const int m = it / nenc, ch = it - m * nenc;
+            if (row0 + m < total) a.d_enc_out[(size_t)(row0 + m) * nenc + ch] = X[mcn_swz(m, ch, XW)];
         }
     }
     // ---- encoding backward -> d xyz -> d rays_o / d rays_d
-    //   enc channel 3+20c+f = w_f sin(2^f x_c), 3+20c+10+f = w_f cos(2^f x_c)  (w_f already inside enc_save)
+    //   enc channel 3+2Fc+f = w_f sin(2^f x_c), 3+2Fc+F+f = w_f cos(2^f x_c)  (w_f already inside enc_save; F = 10 by default)
     if (a.d_rays_o || a.d_rays_d) {
+        const int F = L.nfreq;
         for (int it = tid; it < MT * 3; it += NT) {
             const int m = it / 3, c = it - m * 3;
             const long long g = row0 + m;
@@ -295,10 +297,9 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             if (g < total && !a.d_enc_out) {
                 const float* en = a.enc_save + (size_t)g * MCN_ENCP;
                 dx = X[mcn_swz(m, c, XW)];
-#pragma unroll
-                for (int f = 0; f < MCN_NFREQ; ++f) {
-                    const float s = en[3 + 20 * c + f], co = en[3 + 20 * c + 10 + f];
-                    const float ds = X[mcn_swz(m, 3 + 20 * c + f, XW)], dc = X[mcn_swz(m, 3 + 20 * c + 10 + f, XW)];
+                for (int f = 0; f < F; ++f) {
+                    const float s = en[3 + 2 * F * c + f], co = en[3 + 2 * F * c + F + f];
+                    const float ds = X[mcn_swz(m, 3 + 2 * F * c + f, XW)], dc = X[mcn_swz(m, 3 + 2 * F * c + F + f, XW)];
                     dx += (float)(1 << f) * (co * ds - s * dc);
                 }
             }

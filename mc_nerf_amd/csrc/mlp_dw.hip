@@ -244,14 +244,14 @@ hipError_t mcn_launch_dw(const McnDwArgs& a, hipStream_t st) {
     auto dy = [&](int slot) { return a.dy_save + (size_t)slot * AS; };
     hipError_t e;
     for (int l = 0; l < D; ++l) {
-        const int ldw = mcn_layer_in(L.skip_mask, W, l);
+        const int ldw = mcn_layer_in(L, l);
         const bool takes_enc = l == 0 || ((L.skip_mask >> l) & 1u);
         if (takes_enc) {                  // encoded-input columns
-            DwSeg s = {dy(l), W, a.enc_save, MCN_ENCP, W, 0, W, MCN_ENCP, MCN_ENC, a.grads + L.pW[l], ldw, a.grads + L.pB[l]};
+            DwSeg s = {dy(l), W, a.enc_save, MCN_ENCP, W, 0, W, MCN_ENCP, L.nenc, a.grads + L.pW[l], ldw, a.grads + L.pB[l]};
             if ((e = launch_seg(s, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
         }
         if (l > 0) {                      // hidden-input columns (after the 63 encoded ones at the skip layer)
-            DwSeg s = {dy(l), W, act(l - 1), W, W, 0, W, W, W, a.grads + L.pW[l] + (takes_enc ? MCN_ENC : 0), ldw,
+            DwSeg s = {dy(l), W, act(l - 1), W, W, 0, W, W, W, a.grads + L.pW[l] + (takes_enc ? L.nenc : 0), ldw,
                        takes_enc ? nullptr : a.grads + L.pB[l]};
             if ((e = launch_seg(s, a.count, a.rows, st, a.gmax_bits, a.split16)) != hipSuccess) return e;
         }

@@ -33,27 +33,30 @@ struct FwdSmem {
 // each multiplied by the BARF weight of its frequency (all ones when BARF is off).
 template <int MT, int XW>
 __device__ __forceinline__ void write_encoding(float* X, const float* sxyz, const float* barf_w, int tid, int nthreads,
-                                               const float* enc_in = nullptr, long long row0 = 0, long long total = 0) {
+                                               const float* enc_in = nullptr, long long row0 = 0, long long total = 0, int F = MCN_NFREQ) {
+    // (F = `emb_freqs_xyz` <= 10: 3 + 6 F real channels, [x,y,z, per coord: sin f < F, cos f < F]; the columns up to 64 are zero)
+    const int nenc = 3 + 6 * F;
     if (enc_in) {          // caller-supplied encodings [rows][63] (the stand-alone CorseFine_NeRF.forward, model/net_block.py:67-78)
         for (int it = tid; it < MT * MCN_ENCP; it += nthreads) {
             const int m = it / MCN_ENCP, ch = it - m * MCN_ENCP;
-            X[mcn_swz(m, ch, XW)] = (ch < MCN_ENC && row0 + m < total) ? enc_in[(size_t)(row0 + m) * MCN_ENC + ch] : 0.f;
+            X[mcn_swz(m, ch, XW)] = (ch < nenc && row0 + m < total) ? enc_in[(size_t)(row0 + m) * nenc + ch] : 0.f;
         }
         return;
     }
-    for (int it = tid; it < MT * 30; it += nthreads) {
-        const int m = it / 30, cf = it - m * 30;
-        const int c = cf / 10, f = cf - c * 10;
+    for (int it = tid; it < MT * 3 * F; it += nthreads) {
+        const int m = it / (3 * F), cf = it - m * (3 * F);
+        const int c = cf / F, f = cf - c * F;
         const float v = sxyz[m * 4 + c] * (float)(1 << f);     // exact: power-of-two scale
         float s, co;
         mcn_sincos(v, s, co);
         const float w = barf_w[f];
-        X[mcn_swz(m, 3 + c * 20 + f, XW)] = s * w;
-        X[mcn_swz(m, 3 + c * 20 + 10 + f, XW)] = co * w;
+        X[mcn_swz(m, 3 + c * 2 * F + f, XW)] = s * w;
+        X[mcn_swz(m, 3 + c * 2 * F + F + f, XW)] = co * w;
     }
-    for (int it = tid; it < MT * 4; it += nthreads) {
-        const int m = it >> 2, c = it & 3;
-        X[mcn_swz(m, c == 3 ? 63 : c, XW)] = (c == 3) ? 0.f : sxyz[m * 4 + c];
+    const int npad = MCN_ENCP - nenc;                      // zero columns behind the real channels (1 at F = 10)
+    for (int it = tid; it < MT * (3 + npad); it += nthreads) {
+        const int m = it / (3 + npad), c = it - m * (3 + npad);
+        X[mcn_swz(m, c < 3 ? c : nenc + (c - 3), XW)] = c < 3 ? sxyz[m * 4 + c] : 0.f;
     }
 }
 
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
         saddr[m] = addr;
     }
     __syncthreads();
-    write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT, a.enc_in, row0, total);
+    write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT, a.enc_in, row0, total, L.nfreq);
     __syncthreads();
     if (SAVE) {   // encoded inputs are the X operand of dW for layer 0 and the skip layer
         for (int it = tid; it < MT * 16; it += NT) {
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(McnGeom<WIDTH>::WN * McnGeom<WIDTH>::WM * 64, 2) vo
             mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, KSH, pk + (L.fH[l] >> 2) + (wn * NI) * KSH * 64, lane);
             if ((L.skip_mask >> l) & 1u) {
                 __syncthreads();                       // everyone finished reading h from X
-                write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT, a.enc_in, row0, total);
+                write_encoding<MT, XW>(X, sxyz, a.barf_w, tid, NT, a.enc_in, row0, total, L.nfreq);
                 __syncthreads();
                 mcn_gemm_seg<NI, MI>(acc, X, XW, mrow0, 0, MCN_ENCP / 8, pk + (L.fEncS[l] >> 2) + (wn * NI) * (MCN_ENCP / 8) * 64, lane);
             }

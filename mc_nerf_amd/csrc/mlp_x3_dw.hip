@@ -338,7 +338,7 @@ hipError_t mcnx3_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
     if (D + 5 > DWX3_MAXSEG) return hipErrorInvalidValue;
     const bool merged = (W == 256 || W == 128);       // (DwX3SkipMerged)
     for (int l = 0; l < D; ++l) {
-        const int ldw = mcn_layer_in(L.skip_mask, W, l);
+        const int ldw = mcn_layer_in(L, l);
         float* dWl = a.grads + L.pW[l];
         float* dbl = a.grads + L.pB[l];
         if (l == 0)                       // encoded-input columns only

@@ -73,11 +73,11 @@ static void build_pack_table(const McnLayout& L, PackTable& t) {
         first4 += n_pad * k_pad / 4;
     };
     const int W = L.width;
-    add(L.pW[0], MCN_ENC, 0, W, MCN_ENC, W, MCN_ENCP, L.fEnc0, L.bEnc0);
+    add(L.pW[0], L.nenc, 0, W, L.nenc, W, MCN_ENCP, L.fEnc0, L.bEnc0);
     for (int i = 1; i < L.depth; ++i) {
         if ((L.skip_mask >> i) & 1u) {
-            add(L.pW[i], W + MCN_ENC, 0, W, MCN_ENC, W, MCN_ENCP, L.fEncS[i], L.bEncS[i]);
-            add(L.pW[i], W + MCN_ENC, MCN_ENC, W, W, W, W, L.fH[i], L.bH[i]);
+            add(L.pW[i], W + L.nenc, 0, W, L.nenc, W, MCN_ENCP, L.fEncS[i], L.bEncS[i]);
+            add(L.pW[i], W + L.nenc, L.nenc, W, W, W, W, L.fH[i], L.bH[i]);
         } else {
             add(L.pW[i], W, 0, W, W, W, W, L.fH[i], L.bH[i]);
         }

@@ -194,44 +194,47 @@ hipError_t mcn_launch_cap_random(const int2* idx_in, const int* count, int max_r
 }
 
 // ------------------------------------------------------------------ stand-alone positional encoding
-// SinCosEmbedding.forward (model/net_block.py:20-35): [n,3] -> [n,63] = [x, per axis sin(2^f x) f=0..9, cos(2^f x) f=0..9]
+// SinCosEmbedding.forward (model/net_block.py:20-35): [n,3] -> [n,3+6F] = [x, per axis sin(2^f x) f<F, cos(2^f x) f<F] (F = 10: 63)
 // times the per-frequency BARF weights.  (The render path computes the same inside the fused MLP kernels.)
-__global__ __launch_bounds__(256) void encode_kernel(const float* x, const float* barf_w, int n, float* out) {
+// (F = `emb_freqs_xyz` frequencies, 3 + 6 F output channels; one thread per (point, axis, frequency), F = 0: per (point, axis))
+__global__ __launch_bounds__(256) void encode_kernel(const float* x, const float* barf_w, int n, int F, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * 30) return;
-    const int m = i / 30, cf = i - m * 30, c = cf / 10, f = cf - c * 10;
+    const int per = 3 * (F > 0 ? F : 1), nenc = 3 + 6 * F;
+    if (i >= n * per) return;
+    const int m = i / per, cf = i - m * per, c = F > 0 ? cf / F : cf, f = F > 0 ? cf - c * F : 0;
     const float xv = x[m * 3 + c];
+    if (f == 0) out[(size_t)m * nenc + c] = xv;
+    if (F == 0) return;
     float s, co;
     mcn_sincos(xv * (float)(1 << f), s, co);
     const float w = barf_w[f];
-    out[(size_t)m * MCN_ENC + 3 + c * 20 + f] = s * w;
-    out[(size_t)m * MCN_ENC + 3 + c * 20 + 10 + f] = co * w;
-    if (f == 0) out[(size_t)m * MCN_ENC + c] = xv;
+    out[(size_t)m * nenc + 3 + c * 2 * F + f] = s * w;
+    out[(size_t)m * nenc + 3 + c * 2 * F + F + f] = co * w;
 }
-hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, float* out, hipStream_t st) {
+hipError_t mcn_launch_encode(const float* x, const float* barf_w, int n, int n_freqs, float* out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(encode_kernel, dim3((n * 30 + 255) / 256), dim3(256), 0, st, x, barf_w, n, out);
+    const int per = 3 * (n_freqs > 0 ? n_freqs : 1);
+    hipLaunchKernelGGL(encode_kernel, dim3((n * per + 255) / 256), dim3(256), 0, st, x, barf_w, n, n_freqs, out);
     return hipGetLastError();
 }
 // its backward: d x_c = d out_c + sum_f w_f 2^f (cos(2^f x_c) d sin_f - sin(2^f x_c) d cos_f); one thread per (point, axis)
-__global__ __launch_bounds__(256) void encode_bwd_kernel(const float* x, const float* barf_w, int n, const float* d_out, float* d_x) {
+__global__ __launch_bounds__(256) void encode_bwd_kernel(const float* x, const float* barf_w, int n, int F, const float* d_out, float* d_x) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * 3) return;
     const int m = i / 3, c = i - m * 3;
     const float xv = x[i];
-    const float* g = d_out + (size_t)m * MCN_ENC;
+    const float* g = d_out + (size_t)m * (3 + 6 * F);
     float dx = g[c];
-#pragma unroll
-    for (int f = 0; f < MCN_NFREQ; ++f) {
+    for (int f = 0; f < F; ++f) {
         float s, co;
         mcn_sincos(xv * (float)(1 << f), s, co);
-        dx = fmaf(barf_w[f] * (float)(1 << f), co * g[3 + c * 20 + f] - s * g[3 + c * 20 + 10 + f], dx);
+        dx = fmaf(barf_w[f] * (float)(1 << f), co * g[3 + c * 2 * F + f] - s * g[3 + c * 2 * F + F + f], dx);
     }
     d_x[i] = dx;
 }
-hipError_t mcn_launch_encode_bwd(const float* x, const float* barf_w, int n, const float* d_out, float* d_x, hipStream_t st) {
+hipError_t mcn_launch_encode_bwd(const float* x, const float* barf_w, int n, int n_freqs, const float* d_out, float* d_x, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(encode_bwd_kernel, dim3((n * 3 + 255) / 256), dim3(256), 0, st, x, barf_w, n, d_out, d_x);
+    hipLaunchKernelGGL(encode_bwd_kernel, dim3((n * 3 + 255) / 256), dim3(256), 0, st, x, barf_w, n, n_freqs, d_out, d_x);
     return hipGetLastError();
 }
 

@@ -68,8 +68,8 @@ class NeRF_Model(nn.Module):
         if self.precision not in ops.PRECISIONS:
             raise ValueError(f"precision must be one of {ops.PRECISIONS}")
         if self.precision != "f32" and (self.nerf_coarse.net.fp32_only or self.nerf_fine.net.fp32_only):
-            raise ValueError("a net with more than one skip layer or an SH degree other than 2 runs in precision 'f32' only (the "
-                             f"register-chain kernels of '{self.precision}' take one skip layer and MLP_deg = 2)")
+            raise ValueError("a net with more than one skip layer, an SH degree other than 2 or other than 10 encoding frequencies runs in "
+                             f"precision 'f32' only (the register-chain kernels of '{self.precision}' take one skip layer, MLP_deg = 2, emb_freqs_xyz = 10)")
         self.settings = RenderSettings(self.samples_c, self.sample_scale, float(self.weight_thresh),
                                        float(self.sigma_default), bool(self.white_back), precision=self.precision)
         self.last_selection = None

@@ -27,12 +27,12 @@ class EncodeFn(torch.autograd.Function):
         flat = x.reshape(-1, 3).float().contiguous()
         ctx.save_for_backward(flat, barf_w)
         ctx.shape = x.shape
-        return ops.encode(flat, barf_w).reshape(*x.shape[:-1], 63)
+        return ops.encode(flat, barf_w).reshape(*x.shape[:-1], 3 + 6 * barf_w.numel())
 
     @staticmethod
     def backward(ctx, d_out):
         flat, barf_w = ctx.saved_tensors
-        d_x = ops.encode_bwd(flat, barf_w, d_out.reshape(-1, 63).float().contiguous())
+        d_x = ops.encode_bwd(flat, barf_w, d_out.reshape(-1, 3 + 6 * barf_w.numel()).float().contiguous())
         return d_x.reshape(ctx.shape), None
 
 
@@ -46,7 +46,7 @@ class MlpApplyFn(torch.autograd.Function):
     def forward(ctx, module, x, dirs, flat):
         net = module.net
         packed = ops.pack_weights(net, flat, precision="f32")
-        xe, dd = x.reshape(-1, 63).float().contiguous(), dirs.reshape(-1, 3).float().contiguous()
+        xe, dd = x.reshape(-1, net.n_enc).float().contiguous(), dirs.reshape(-1, 3).float().contiguous()
         out, save = ops.mlp_apply_save(net, flat, packed, xe, dd)
         ctx.net, ctx.save, ctx.packed = net, save, packed
         ctx.save_for_backward(flat, dd, out)
@@ -76,8 +76,8 @@ class SinCosEmbedding(nn.Module):
         self.sys_param = sys_params
         self.device = sys_params["device_type"]
         self.n_freqs = sys_params["emb_freqs_xyz"]
-        if self.n_freqs != 10:
-            raise ValueError("the HIP kernels are built for emb_freqs_xyz = 10 (63 encoded channels)")
+        if not 1 <= self.n_freqs <= 10:
+            raise ValueError("1 .. 10 encoding frequencies are built (emb_freqs_xyz; 64-column encoded-input tiles)")
         self.barf_mode = sys_params["barf_mask"]
         self.barf_start = sys_params["barf_start"]
         self.barf_end = sys_params["barf_end"]
@@ -124,17 +124,19 @@ class CorseFine_NeRF(nn.Module):
         super().__init__()
         self.in_channels_xyz = 3 * (2 * sys_params["emb_freqs_xyz"] + 1)
         self.deg = sys_params["MLP_deg"]
-        if self.in_channels_xyz != 63:
-            raise ValueError("the HIP kernels are built for 63 encoded channels (emb_freqs_xyz = 10)")
+        self.n_freqs = int(sys_params["emb_freqs_xyz"])
+        if not 1 <= self.n_freqs <= 10:
+            raise ValueError("1 .. 10 encoding frequencies are built (emb_freqs_xyz; 64-column encoded-input tiles)")
         if not 0 <= self.deg <= 3:
             raise ValueError("SH degrees 0 .. 3 are built (MLP_deg)")
         key = "coarse" if type == "coarse" else "fine"
         self.depth = sys_params[f"{key}_MLP_depth"]
         self.width = sys_params[f"{key}_MLP_width"]
         self.skips = list(sys_params[f"{key}_MLP_skip"])
-        # any `skips` list (reference :45, 55-58) and SH degree 0 .. 3 (:43, 75-76); more than one skip layer or a degree other than 2 run on the exact-fp32 kernel family only
+        # any `skips` list (reference :45, 55-58), SH degree 0 .. 3 (:43, 75-76) and 0 .. 10 encoding frequencies (:11-18); more than one
+        # skip layer, a degree other than 2 or a frequency count other than 10 run on the exact-fp32 kernel family only
         # (NeRF_Model refuses the register-chain precision modes for such a net)
-        self.net = ops.Net(self.depth, self.width, ops.skip_code(self.skips, self.depth, self.deg))
+        self.net = ops.Net(self.depth, self.width, ops.skip_code(self.skips, self.depth, self.deg, self.n_freqs))
         for i in range(self.depth):
             fan_in = self.net.in_features(i)
             setattr(self, f"xyz_encoding_{i+1}", nn.Sequential(nn.Linear(fan_in, self.width), nn.ReLU(True)))
@@ -213,7 +215,7 @@ class CorseFine_NeRF(nn.Module):
             return MlpApplyFn.apply(self, x, dirs, self.flat_params_autograd())
         flat = self.flat_params()
         packed = ops.pack_weights(self.net, flat, precision="f32")
-        return ops.mlp_apply(self.net, flat, packed, x.detach().reshape(-1, 63).float().contiguous(),
+        return ops.mlp_apply(self.net, flat, packed, x.detach().reshape(-1, self.net.n_enc).float().contiguous(),
                              dirs.detach().reshape(-1, 3).float().contiguous()).reshape(*x.shape[:-1], 4)
 
 

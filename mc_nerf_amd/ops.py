@@ -19,18 +19,21 @@ Tensor = torch.Tensor
 SKIP_MASK = 256          # MCN_SKIP_MASK: skip >= 256 = (bit mask of skip layers) << 8 (include/mcnerf.h)
 
 
-def skip_code(skips, depth: int, deg: int = 2) -> int:
-    """The reference's `skips` list and `MLP_deg` (model/net_block.py:43-45) -> the C ABI's `skip` argument: -1 (no skip layer),
-    the layer index (one), or the mask form -- (bit mask of skip layers | 1) << 8, with 0x80 | deg << 4 in the low byte when the SH
-    degree is not 2 (several skip layers or another degree: exact-fp32 kernels only)."""
+def skip_code(skips, depth: int, deg: int = 2, n_freqs: int = 10) -> int:
+    """The reference's `skips` list, `MLP_deg` and `emb_freqs_xyz` (model/net_block.py:11-18, 43-45) -> the C ABI's `skip` argument:
+    -1 (no skip layer), the layer index (one), or the mask form -- (bit mask of skip layers | 1) << 8, with 0x80 | deg << 4 in the low
+    byte when the SH degree is not 2 and n_freqs + 1 in its low nibble when that is not 10 (several skip layers, another degree or
+    frequency count: exact-fp32 kernels only)."""
     ks = sorted({int(k) for k in skips if 0 < int(k) < depth})
     if not 0 <= deg <= 3:
         raise ValueError("SH degrees 0 .. 3 are built")
-    if deg == 2 and not ks:
+    if not 1 <= n_freqs <= 10:
+        raise ValueError("1 .. 10 encoding frequencies are built (64-column encoded-input tiles)")
+    if deg == 2 and n_freqs == 10 and not ks:
         return -1
-    if deg == 2 and len(ks) == 1:
+    if deg == 2 and n_freqs == 10 and len(ks) == 1:
         return ks[0]
-    return ((sum(1 << k for k in ks) | 1) << 8) | ((0x80 | (deg << 4)) if deg != 2 else 0)
+    return ((sum(1 << k for k in ks) | 1) << 8) | ((0x80 | (deg << 4)) if deg != 2 else 0) | ((n_freqs + 1) if n_freqs != 10 else 0)
 
 
 @dataclass(frozen=True)
@@ -68,14 +71,22 @@ class Net:
         return 32 if self.n_sh < 32 else 64
 
     @property
+    def n_freqs(self) -> int:
+        return (self.skip & 15) - 1 if self.skip >= SKIP_MASK and self.skip & 15 else 10
+
+    @property
+    def n_enc(self) -> int:
+        return 3 + 6 * self.n_freqs
+
+    @property
     def fp32_only(self) -> bool:
-        """Topologies only the exact-fp32 kernel family takes (the register-chain modes: one skip layer, SH degree 2)."""
-        return self.multi_skip or self.deg != 2
+        """Topologies only the exact-fp32 kernel family takes (the register-chain modes: one skip layer, SH degree 2, 10 frequencies)."""
+        return self.multi_skip or self.deg != 2 or self.n_freqs != 10
 
     def in_features(self, i: int) -> int:
         if i == 0:
-            return 63
-        return self.width + 63 if i in self.skips else self.width
+            return self.n_enc
+        return self.width + self.n_enc if i in self.skips else self.width
 
     def shapes(self):
         """Tensor shapes in the reference's state-dict order."""
@@ -292,10 +303,10 @@ def upload_f32(host_vals: Tensor, device) -> Tensor:
 
 
 def encode(x: Tensor, barf_w: Tensor) -> Tensor:
-    """SinCosEmbedding.forward (model/net_block.py:20-35): [n,3] -> [n,63]."""
-    n = x.shape[0]
-    out = torch.empty(n, 63, dtype=torch.float32, device=x.device)
-    _lib.call("mcnerf_encode", _p(x), _p(barf_w), n, _p(out), _stream())
+    """SinCosEmbedding.forward (model/net_block.py:20-35): [n,3] -> [n, 3 + 6 F] with F = len(barf_w) frequencies (10: 63)."""
+    n, F = x.shape[0], barf_w.numel()
+    out = torch.empty(n, 3 + 6 * F, dtype=torch.float32, device=x.device)
+    _lib.call("mcnerf_encode", _p(x), _p(barf_w), n, F, _p(out), _stream())
     return out
 
 
@@ -315,10 +326,10 @@ def sync_finish(arena: Tensor, n_grad: int, world: int, local_flags: Tensor, asy
 
 
 def encode_bwd(x: Tensor, barf_w: Tensor, d_out: Tensor) -> Tensor:
-    """Backward of `encode`: d_out [n,63] -> d_x [n,3]."""
+    """Backward of `encode`: d_out [n, 3 + 6 F] -> d_x [n,3]."""
     n = x.shape[0]
     d_x = torch.empty(n, 3, dtype=torch.float32, device=x.device)
-    _lib.call("mcnerf_encode_bwd", _p(x), _p(barf_w), n, _p(d_out), _p(d_x), _stream())
+    _lib.call("mcnerf_encode_bwd", _p(x), _p(barf_w), n, barf_w.numel(), _p(d_out), _p(d_x), _stream())
     return d_x
 
 
@@ -339,7 +350,7 @@ def mlp_apply_bwd(net: Net, params: Tensor, packed: Tensor, dirs: Tensor, out: T
     n = dirs.shape[0]
     dev = dirs.device
     dy, dsh = torch.empty_like(save.act), torch.empty_like(save.sh)
-    d_x = torch.empty(n, 63, dtype=torch.float32, device=dev)
+    d_x = torch.empty(n, net.n_enc, dtype=torch.float32, device=dev)
     z = torch.zeros(n * 3 + 1, dtype=torch.float32, device=dev)          # (d_dirs accumulator + the zero sample depth, one fill)
     d_dirs = z[:n * 3].view(n, 3)
     _lib.call("mcnerf_mlp_apply_bwd", *net.triple, _p(params), _p(packed), _p(dirs), _p(z[n * 3:]), n, _p(out), _p(d_out),

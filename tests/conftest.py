@@ -37,14 +37,16 @@ def cfg_from_golden(g):
         kw.update(barf_start=float(g["barf"][0]), barf_end=float(g["barf"][1]))
     if "deg" in g:
         kw.update(deg=int(g["deg"]))
+    if "n_freqs" in g:
+        kw.update(n_freqs=int(g["n_freqs"]))
     return O.RenderCfg(**kw)
 
 
 def nets_from_golden(g, cfg):
     from oracle import mcnerf_oracle as O
-    n_sh = 3 * (cfg.deg + 1) ** 2
-    pc = O.init_params(cfg.coarse, int(g["seed_c"]), n_sh=n_sh)
-    pf = O.init_params(cfg.fine, int(g["seed_f"]), n_sh=n_sh)
+    n_sh, in_ch = 3 * (cfg.deg + 1) ** 2, 3 + 6 * cfg.n_freqs
+    pc = O.init_params(cfg.coarse, int(g["seed_c"]), in_ch=in_ch, n_sh=n_sh)
+    pf = O.init_params(cfg.fine, int(g["seed_f"]), in_ch=in_ch, n_sh=n_sh)
     s = float(g["sigma_shift"])
     if s:
         pc["sigma.2.bias"] = pc["sigma.2.bias"] + s

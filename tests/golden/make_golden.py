@@ -110,8 +110,8 @@ def npz(name, **arrs):
 
 
 def load_nets(model: NeRF_Model, cfg: O.RenderCfg, seed_c, seed_f, sigma_bias_shift=0.0):
-    n_sh = 3 * (cfg.deg + 1) ** 2
-    pc, pf = O.init_params(cfg.coarse, seed_c, n_sh=n_sh), O.init_params(cfg.fine, seed_f, n_sh=n_sh)
+    n_sh, in_ch = 3 * (cfg.deg + 1) ** 2, 3 + 6 * cfg.n_freqs
+    pc, pf = O.init_params(cfg.coarse, seed_c, in_ch=in_ch, n_sh=n_sh), O.init_params(cfg.fine, seed_f, in_ch=in_ch, n_sh=n_sh)
     if sigma_bias_shift:
         pc["sigma.2.bias"] = pc["sigma.2.bias"] + sigma_bias_shift
         pf["sigma.2.bias"] = pf["sigma.2.bias"] + sigma_bias_shift
@@ -197,7 +197,7 @@ def g7_train(tag, cfg: O.RenderCfg, n, seed, step_r, sigma_shift=0.0, only_coars
                               cfg.fine.depth, cfg.fine.width, cfg.fine.skips[0], int(cfg.barf_mode)]),
                 barf=np.array([cfg.barf_start, cfg.barf_end]),
                 skips_c=np.array(cfg.coarse.skips), skips_f=np.array(cfg.fine.skips),      # (the whole `skips` lists; `cfg` holds the first entries)
-                deg=cfg.deg)
+                deg=cfg.deg, n_freqs=cfg.n_freqs)
     if only_coarse:
         arrs["depth_c"] = depth_c
     else:
@@ -399,8 +399,17 @@ def g7_sh_degrees():
         g7_train(f"g7_train_s32x2_deg{deg}", O.RenderCfg(samples=32, scale=2, deg=deg, **small), 72, 77 + deg, 1.0)
 
 
+def g7_n_freqs():
+    """General topology: `emb_freqs_xyz` = 6 (39 encoded channels, model/net_block.py:11-18) with the BARF mask on (alpha scales with
+    the frequency count, :27) and SH degree 1; one small train render + backward of the actual reference."""
+    g7_train("g7_train_s32x2_freq6_barf", O.RenderCfg(samples=32, scale=2, n_freqs=6, deg=1, barf_mode=True, barf_start=0.3846, barf_end=0.6923,
+                                                       coarse=O.NetCfg(4, 32, (2,)), fine=O.NetCfg(8, 64, (4,))), 72, 81, 0.55)
+
+
 def main():
     torch.set_num_threads(4)
+    if "--only-n-freqs" in sys.argv:
+        return g7_n_freqs()
     if "--only-sh-degrees" in sys.argv:
         return g7_sh_degrees()
     if "--only-full-size" in sys.argv:
@@ -409,6 +418,7 @@ def main():
         return g7_multi_skip()
     g7_multi_skip()
     g7_sh_degrees()
+    g7_n_freqs()
     g7_sh_degrees()
     g7_full_size()
     g11_mc_model_step()

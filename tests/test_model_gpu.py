@@ -158,18 +158,21 @@ def test_multi_skip_topology_matches_reference(gpu_device):
             NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision=precision))
 
 
-@pytest.mark.parametrize("deg", [0, 1, 3])
-def test_sh_degree_topology_matches_reference(gpu_device, deg):
+@pytest.mark.parametrize("name", ["g7_train_s32x2_deg0", "g7_train_s32x2_deg1", "g7_train_s32x2_deg3", "g7_train_s32x2_freq6_barf"])
+def test_sh_degree_topology_matches_reference(gpu_device, name):
     """General topology: `MLP_deg` 0, 1, 3 (model/net_block.py:43, 75-76; eval_sh up to degree 3, model/net_utils.py:103-179): 3, 12, 48
-    sh.2 outputs.  Train render + backward against the golden captured from the actual reference on the exact-fp32 kernel family
-    (templated per degree; degree 3 runs sh.2 as two 32-row tiles), incl. the view-direction gradient through the basis
-    derivatives; the register-chain precision modes refuse the net."""
+    sh.2 outputs; and `emb_freqs_xyz` = 6 (39 encoded channels, :11-18) with the BARF mask on and degree 1.  Train render + backward
+    against the goldens captured from the actual reference on the exact-fp32 kernel family (SH head templated per degree, degree 3
+    as two 32-row tiles of sh.2; the encoding with its real channels packed in front of zero columns), incl. the view-direction
+    gradient through the basis derivatives; the register-chain precision modes refuse the nets."""
     from mc_nerf_amd.model import MC_NeRF_Loss, NeRF_Model
-    g = load_golden(f"g7_train_s32x2_deg{deg}")
+    g = load_golden(name)
     dev = gpu_device
     m, cfg, pc, pf = build_model(g, dev, precision="f32")
+    deg = cfg.deg
     n_sh = 3 * (deg + 1) ** 2
-    assert cfg.deg == deg and m.nerf_fine.sh[2].weight.shape == (n_sh, 64) and m.nerf_fine.net.deg == deg
+    assert m.nerf_fine.sh[2].weight.shape == (n_sh, 64) and m.nerf_fine.net.deg == deg
+    assert m.nerf_fine.xyz_encoding_1[0].weight.shape == (64, 3 + 6 * cfg.n_freqs) and m.nerf_fine.net.n_freqs == cfg.n_freqs
     d = t(g["rays_d"]).to(dev).requires_grad_(True)
     o = t(g["rays_o"]).to(dev).requires_grad_(True)
     rgb_c, rgb_f = m.render_rays_train(d, o, 0, float(g["step_r"]), jitter=t(g["jitter"]).to(dev), eps_c=t(g["eps_c"]).to(dev),
@@ -198,7 +201,7 @@ def test_sh_degree_topology_matches_reference(gpu_device, deg):
             # touch -- one ReLU decision), or 8 x what the reference arithmetic itself does to this tensor under a re-ordering of the
             # hidden units (degree 0: the coarse sigma gradients nearly cancel -- |d b_sigma2| = 6e-7 -- and that noise alone is 1.1e-4)
             assert e < max(3e-4, 8.0 * noise[f"{tag}.{k_}"]), (tag, k_, e, noise[f"{tag}.{k_}"])
-    print(f"MLP_deg = {deg} ({n_sh} sh.2 outputs) vs the reference's golden: rgb {max(err(rgb_c, g['rgb_c']), err(rgb_f, g['rgb_f'])):.1e}, "
+    print(f"MLP_deg = {deg} ({n_sh} sh.2 outputs), emb_freqs_xyz = {cfg.n_freqs} vs the reference's golden: rgb {max(err(rgb_c, g['rgb_c']), err(rgb_f, g['rgb_f'])):.1e}, "
           f"d_rays_d {e_d:.1e}, worst parameter gradient {worst:.1e} of its tensor's max")
     with torch.no_grad():
         r = O.render_rays_test(pc, pf, cfg, t(g["rays_d"]), t(g["rays_o"]), t(g["eps_c"]), t(g["eps_sel"]), t(g["eps_f"]))
@@ -207,6 +210,16 @@ def test_sh_degree_topology_matches_reference(gpu_device, deg):
     assert float((rgb.cpu() - r["rgb"]).abs().max()) < TOL
     with pytest.raises(ValueError, match="SH degree other than 2"):
         NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision="f16x3"))
+    # the stand-alone module forwards of the same topology (SinCosEmbedding.forward / CorseFine_NeRF.forward, differentiable)
+    x = (t(g["rays_o"])[:40] + t(g["rays_d"])[:40] * 2.5).to(dev).requires_grad_(True)
+    enc = m.emmbedding_xyz(x, float(g["step_r"]))
+    ref_enc = O.embed(x.detach().cpu(), float(g["step_r"]), cfg)
+    assert enc.shape == (40, 3 + 6 * cfg.n_freqs) and float((enc.detach().cpu() - ref_enc).abs().max()) < 2e-6
+    out = m.nerf_fine(enc, t(g["rays_d"])[:40].to(dev))
+    ref_out = O.mlp_forward(pf, cfg.fine, ref_enc, t(g["rays_d"])[:40])
+    assert float((out.detach().cpu() - ref_out.detach()).abs().max()) < 1e-5
+    out.square().sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
 
 
 # per mode: (rgb abs, worst per-tensor gradient error as a multiple of the reference's own worst reorder noise, median over the
