@@ -211,7 +211,7 @@ int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows
 // ---- register-chain modes: single-pass 16-bit (mcnerf_16.h; dtype 0 = f16, 1 = bf16) and split-f16 "f16x3" (mcnerf_x3.h; dtype 2)
 static bool dtype_ok(int dtype) { return dtype == 0 || dtype == 1 || dtype == 2; }
 long long mcnerf_packed_bytes_16(int depth, int width, int skip, int dtype, int backward) {
-    if (!net_ok(depth, width, skip) || !dtype_ok(dtype)) return -1;
+    if (!net16_ok(depth, width, skip) || !dtype_ok(dtype)) return -1;
     const McnLayout L = mcn_make_layout(depth, width, skip);
     if (dtype == 2) return (long long)(backward ? mcnx3_bwd_stream(L) : mcnx3_fwd_stream(L)).total_frags * 2048;
     return (long long)(backward ? mcn16_bwd_stream(L) : mcn16_fwd_stream(L)).total_frags * 1024;

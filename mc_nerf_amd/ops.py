@@ -201,6 +201,7 @@ RANGE_TEXT = {"f16": "|w| <= 65504", "bf16": "finite weights", "f16x3": "|w| <= 
 
 def range_watch_register(flags: Tensor, label: str, names, precision: str):
     import weakref
+    _RANGE_WATCH[:] = [w for w in _RANGE_WATCH if w[0]() is not None]         # (models come and go: drop the words of dead ones)
     _RANGE_WATCH.append((weakref.ref(flags), label, list(names), precision))
 
 

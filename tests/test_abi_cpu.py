@@ -59,3 +59,40 @@ def test_ops_refuse_cpu_tensors(built_lib):
     net = ops.Net(4, 32, 2)
     with pytest.raises(_lib.McnerfError):
         ops.pack_weights(net, torch.zeros(ops.param_count(net)), torch.zeros(ops.packed_count(net)))
+
+
+def test_general_topology_codes_and_layouts(built_lib):
+    """The `skip` argument's mask form (include/mcnerf.h): any `skips` list, SH degree 0 .. 3, 1 .. 10 encoding frequencies.  The flat
+    parameter layout of such a net is the reference's state dict (model/net_block.py:51-65) in order, every tensor 16-byte aligned;
+    the default topology keeps its legacy codes; the register-chain entry points refuse what they do not take."""
+    import numpy as np
+    from mc_nerf_amd import ops
+    l = ops._lib.lib()
+    assert ops.skip_code([4], 8) == 4 and ops.skip_code([], 4) == -1 and ops.skip_code([0, 9], 8) == -1        # (0 and >= depth are not skip layers)
+    code = ops.skip_code([2, 4, 6], 8)
+    net = ops.Net(8, 64, code)
+    assert code >= ops.SKIP_MASK and net.skips == [2, 4, 6] and net.multi_skip and net.deg == 2 and net.n_freqs == 10
+    assert [net.in_features(i) for i in range(8)] == [63, 64, 127, 64, 127, 64, 127, 64]
+    g = ops.Net(4, 32, ops.skip_code([2], 4, deg=3, n_freqs=6))
+    assert (g.skips, g.deg, g.n_sh, g.n_shp, g.n_freqs, g.n_enc) == ([2], 3, 48, 64, 6, 39)
+    assert g.fp32_only and net.fp32_only and not ops.Net(8, 256, 4).fp32_only
+    for n_ in (net, g, ops.Net(4, 128, ops.skip_code([1, 3], 4, deg=0)), ops.Net(8, 256, 4)):
+        offs, shapes = ops.param_offsets(n_), n_.shapes()
+        assert len(offs) == len(shapes) == 2 * n_.depth + 8
+        end = 0
+        for o, shp in zip(offs, shapes):
+            assert o % 4 == 0 and end <= o < end + 4          # next 16-byte boundary after the previous tensor
+            end = o + int(np.prod(shp))
+        assert end <= ops.param_count(n_) < end + 4
+        assert ops.packed_count(n_) > 0
+    assert ops.param_count(ops.Net(8, 256, ops.skip_code([4], 8))) == ops.param_count(ops.Net(8, 256, 4))
+    # refused: degree 4, 11 frequencies, a mask bit at or above the depth; the register-chain sizes of a net they do not take
+    assert l.mcnerf_param_count(4, 32, (1 << 8) | 0x80 | (4 << 4)) == -1
+    assert l.mcnerf_param_count(4, 32, (1 << 8) | 12) == -1
+    assert l.mcnerf_param_count(4, 32, (1 << 8) | (1 << 13)) == -1
+    assert l.mcnerf_packed_bytes_16(*net.triple, 2, 0) == -1 and l.mcnerf_packed_bytes_16(*g.triple, 0, 0) == -1
+    assert l.mcnerf_packed_bytes_16(8, 256, 4, 2, 0) > 0
+    with pytest.raises(ValueError):
+        ops.skip_code([2], 4, deg=4)
+    with pytest.raises(ValueError):
+        ops.skip_code([2], 4, n_freqs=11)

@@ -1277,3 +1277,52 @@ def test_refused_step_names_the_weight_tensor_out_of_range(gpu_device, precision
     assert ("fine net", "xyz_encoding_3.0.weight", precision) in ops.range_report()
     with pytest.raises(_lib.McnerfError, match=r"fine net xyz_encoding_3\.0\.weight"):
         opt.raise_on_overflow()
+
+
+def test_workspace_pool_reuses_the_step_workspaces(gpu_device):
+    """The kernels' saved-operand / gradient workspaces are sized once per model and handed from step to step
+    (render.WorkspacePool; NeRF_Model.reserve_workspaces): the same buffers serve every step, nothing is allocated per step, and a
+    second forward before the first backward gets a set of its own (a forward never overwrites operands a pending backward needs)."""
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd.model import MC_NeRF_Loss, NeRF_Model
+    dev = gpu_device
+    N = 512
+    sp = S.make_sys_param(dev, samples=32, scale=2, batch=N, H=32, W=32, coarse=(4, 32, [2]), fine=(8, 64, [4]), precision="f16x3")
+    torch.manual_seed(1)
+    m = NeRF_Model(sp).to(dev)
+    m.reserve_workspaces(N)
+    pool = m.ws_pool
+    ptrs0 = sorted(ws.act.data_ptr() for key, lst in pool.free.items() if key[0] == "save" for ws in lst)
+    assert len(ptrs0) == 2 and sum(len(v) for v in pool.free.values()) == 4          # (save + grad) x (coarse, fine)
+    g = torch.Generator().manual_seed(2)
+    o = (torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1) * 3.0).to(dev)
+    d = torch.nn.functional.normalize(-o.cpu() + 0.3 * torch.randn(N, 3, generator=g), dim=-1).to(dev)
+    gt = torch.rand(N, 3, generator=g).to(dev)
+    loss_fn = MC_NeRF_Loss(sp)
+
+    def forward():
+        rgb_c, rgb_f = m.render_rays_train(d, o, 0, 1.0)
+        return loss_fn.get_rgb_loss([rgb_c, rgb_f, gt])
+    forward().backward()
+    torch.cuda.synchronize()
+    mem = torch.cuda.memory_allocated(dev)
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        forward().backward()
+    torch.cuda.synchronize()
+    ptrs1 = sorted(ws.act.data_ptr() for key, lst in pool.free.items() if key[0] == "save" for ws in lst)
+    assert ptrs1 == ptrs0 and sum(len(v) for v in pool.free.values()) == 4
+    assert torch.cuda.memory_allocated(dev) <= mem + (1 << 20)                       # steady state: no growth step over step
+    # two graphs alive at once: the second forward must not take the set the first backward still needs
+    l1 = forward()
+    assert sum(len(v) for key, v in pool.free.items() if key[0] == "save") == 0
+    l2 = forward()
+    g1 = torch.autograd.grad(l1, m.nerf_fine.sigma[0].weight, retain_graph=False)[0].clone()
+    m.zero_grad(set_to_none=True)
+    l2.backward()
+    assert sum(len(v) for key, v in pool.free.items() if key[0] == "save") == 4     # both sets came back
+    m.zero_grad(set_to_none=True)
+    forward().backward()
+    ref = m.nerf_fine.sigma[0].weight.grad
+    # (the draws differ from call to call -- device RNG -- so only finiteness and the order of magnitude are comparable)
+    assert torch.isfinite(g1).all() and torch.isfinite(ref).all() and float(g1.abs().max()) > 0.0
