@@ -419,7 +419,6 @@ def main():
     g7_multi_skip()
     g7_sh_degrees()
     g7_n_freqs()
-    g7_sh_degrees()
     g7_full_size()
     g11_mc_model_step()
     g11_mc_model_step("CAM_PARAM_EPOCH", "g11b_mc_model_cam_param", extr_shift=0.7)
