@@ -315,6 +315,12 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
         def nograd_step(i):
             model((images, torch.tensor([cams[i % len(cams)]]), wpts, pts, wpts, pts), 20, "GLOBAL_OPTIM_EPOCH", 0.6)
         shift, got = calibrate_occupancy(model, nograd_step, occupancy, rays * samples * scale)
+        if world > 1:                                  # one shift for the job (rank 0's): the parameters stay identical on every rank
+            t = torch.tensor([shift], device=dev, dtype=torch.float64)
+            dist.broadcast(t, 0)
+            with torch.no_grad():
+                model.nerf.nerf_coarse.sigma[2].bias.add_(float(t.item()) - shift)
+            shift = float(t.item())
         occ = {"target": occupancy, "sigma_bias_shift": shift, "selected_fraction_at_calibration": got}
 
     def step(i, timed):

@@ -866,6 +866,10 @@ def test_bench_two_ranks_share_one_gpu(gpu_device):
     assert j["params_identical_across_ranks"] is True and j["asymmetric_grad_steps"] == 0 and j["finite"] is True
     assert j["allreduce_ms"] > 0 and j["value"] > 0
     assert j["config"]["rays_per_step_per_gpu"] == 2048 and j["config"]["parallelism"].startswith("dp2")
+    for rho, modes in j["by_occupancy"].items():          # the occupancy shift is rank 0's on every rank: the DDP invariant holds on these lines too
+        for p, rec in modes.items():
+            assert rec["params_identical_across_ranks"] is True and rec["asymmetric_grad_steps"] == 0 and rec["valid"], (rho, p, rec)
+            assert abs(rec["selected_fraction"] - float(rho)) < 0.5 * float(rho), (rho, p, rec["selected_fraction"])
 
 
 # ---------------------------------------------------------------------------------------------------------
