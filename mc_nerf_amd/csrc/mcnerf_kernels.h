@@ -124,7 +124,10 @@ struct McnSelectArgs {
     float* out_f;             // [N,Sc*scale,4] prefilled with (sigma_default,1,1,1), or null
 };
 hipError_t mcn_launch_select(const McnSelectArgs& a, hipStream_t st);
-#define MCN_CAP_WS 131080      // uint32 words of mcn_launch_cap_random's workspace
+#define MCN_CAP_BLOCKS 2048     // workgroups (= list chunks) of the cap's passes
+#define MCN_CAP_LT 131080       // per-chunk counts: keys below the threshold ...
+#define MCN_CAP_EQ (MCN_CAP_LT + MCN_CAP_BLOCKS)      // ... and equal to it
+#define MCN_CAP_WS (MCN_CAP_EQ + MCN_CAP_BLOCKS)      // uint32 words of mcn_launch_cap_random's workspace
 hipError_t mcn_launch_cap_random(const int2* idx_in, const int* count, int max_rows, int keep, const unsigned* seed, unsigned* ws,
                                  int2* idx_out, int* count_out, hipStream_t st);
 hipError_t mcn_launch_cap_gather(const int2* idx_in, const long long* perm, int keep, int2* idx_out, int* count, hipStream_t st);

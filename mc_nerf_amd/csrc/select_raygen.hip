@@ -98,10 +98,10 @@ hipError_t mcn_launch_cap_gather(const int2* idx_in, const long long* perm, int 
 // ---- The random cap of model/mc_nerf.py:630-632 without a host round trip.  The reference keeps idx[randperm(K)[:keep]]
 // when K > keep: a uniformly random subset of size `keep` (the order of the list never reaches a result).  Here every
 // entry i < K gets a 32-bit key hash(seed, i) and the `keep` smallest keys are kept: two 65536-bin histogram passes find
-// the exact threshold key, one pass appends the kept entries (wave-aggregated atomics).  K <= keep keeps everything.
+// the exact threshold key, a counting pass and an ordered compaction write the kept entries in list order.  K <= keep keeps everything.
 // ws (uint32): [0 .. 65535] histogram of the high 16 key bits, [65536 .. 131071] histogram of the low 16 bits inside the
 // boundary bin, [131072] boundary bin (0x10000 = keep all), [131073] entries below it, [131074] threshold key,
-// [131075] ties to take at the threshold, [131076] tie counter, [131077] output cursor.
+// [131075] ties to take at the threshold, [MCN_CAP_LT + b] / [MCN_CAP_EQ + b] entries of chunk b below / at the threshold.
 __device__ __forceinline__ unsigned cap_key(unsigned seed, unsigned i) {
     unsigned x = i * 0x9E3779B9u + seed;          // murmur3 finaliser: every output bit depends on every input bit
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
@@ -155,40 +155,81 @@ __global__ __launch_bounds__(1024) void cap_find_lo_kernel(const int* count, int
         ws[131075] = (unsigned)keep - ws[131073] - below;            // ... and this many entries with exactly that key
     }
 }
+// The kept entries keep their order in the list (the reference's order whenever the cap does not bind, and a list that is the same,
+// entry for entry, from run to run when it does: no atomic decides a position): every workgroup owns one contiguous chunk of
+// the list, counts what it keeps (keys below the threshold, keys equal to it), and writes behind the chunks before it; of the entries
+// whose key EQUALS the threshold the first `ties` in list order are taken.
+__device__ __forceinline__ int cap_chunk(int K, int grid) { return (((K + grid - 1) / grid) + 255) & ~255; }
+__global__ __launch_bounds__(256) void cap_count_kernel(const int* count, int max_rows, int keep, const unsigned* seed, unsigned* ws) {
+    const int K = min(*count, max_rows);
+    if (K <= keep) return;
+    const unsigned sd = *seed, thr = ws[131074];
+    const int chunk = cap_chunk(K, gridDim.x), lo = blockIdx.x * chunk, hi = min(K, lo + chunk);
+    unsigned lt = 0, eq = 0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        const unsigned k = cap_key(sd, (unsigned)i);
+        lt += k < thr; eq += k == thr;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lt += __shfl_xor(lt, o); eq += __shfl_xor(eq, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&ws[MCN_CAP_LT + blockIdx.x], lt); atomicAdd(&ws[MCN_CAP_EQ + blockIdx.x], eq); }     // (integer sums: order-free)
+}
+// exclusive rank of `flag` among the 256 threads of the workgroup (in thread order) and the workgroup's total
+__device__ __forceinline__ unsigned cap_block_rank(bool flag, unsigned* wsum, unsigned& total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    __syncthreads();
+    if (lane == 0) wsum[wv] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const unsigned v = wsum[w]; before += w < wv ? v : 0u; total += v; }
+    return before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
 __global__ __launch_bounds__(256) void cap_write_kernel(const int2* idx_in, const int* count, int max_rows, int keep, const unsigned* seed,
                                                         unsigned* ws, int2* idx_out, int* count_out) {
+    __shared__ unsigned wsum[4], red[8];
     const int K = min(*count, max_rows);
-    const unsigned sd = *seed, thr = ws[131074], ties = ws[131075];
-    const int lane = threadIdx.x & 63;
-    const int rounds = (K + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
-    for (int r = 0; r < rounds; ++r) {
-        const int i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;       // consecutive entries stay together
-        bool sel = false;
-        if (i < K) {
-            if (K <= keep) sel = true;
-            else {
-                const unsigned k = cap_key(sd, (unsigned)i);
-                sel = k < thr || (k == thr && atomicAdd(&ws[131076], 1u) < ties);
-            }
-        }
-        const unsigned long long m = __ballot(sel);
-        unsigned base = 0;
-        if (lane == 0 && m) base = atomicAdd(&ws[131077], (unsigned)__popcll(m));
-        base = __shfl(base, 0);
-        if (sel) idx_out[base + __popcll(m & ((1ull << lane) - 1ull))] = idx_in[i];
-    }
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = min(K, keep);
+    const int chunk = cap_chunk(K, gridDim.x), lo = blockIdx.x * chunk, hi = min(K, lo + chunk);
+    if (K <= keep) {                                  // nothing to drop: the list as it stands
+        for (int i = lo + threadIdx.x; i < hi; i += 256) idx_out[i] = idx_in[i];
+        return;
+    }
+    const unsigned sd = *seed, thr = ws[131074], ties = ws[131075];
+    unsigned lt = 0, eq = 0;                          // kept / tied entries of the chunks in front of this one
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) { lt += ws[MCN_CAP_LT + b]; eq += ws[MCN_CAP_EQ + b]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lt += __shfl_xor(lt, o); eq += __shfl_xor(eq, o); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = lt; red[4 + (threadIdx.x >> 6)] = eq; }
+    __syncthreads();
+    lt = red[0] + red[1] + red[2] + red[3];
+    unsigned eq_run = red[4] + red[5] + red[6] + red[7];
+    unsigned pos = lt + min(eq_run, ties);
+    for (int base = lo; base < hi; base += 256) {
+        const int i = base + threadIdx.x;
+        const unsigned k = i < hi ? cap_key(sd, (unsigned)i) : 0xFFFFFFFFu;
+        const bool is_eq = i < hi && k == thr;
+        unsigned n_eq, n_sel;
+        const unsigned tie_rank = cap_block_rank(is_eq, wsum, n_eq);
+        const bool sel = i < hi && (k < thr || (is_eq && eq_run + tie_rank < ties));
+        const unsigned rank = cap_block_rank(sel, wsum, n_sel);
+        if (sel) idx_out[pos + rank] = idx_in[i];
+        pos += n_sel; eq_run += n_eq;
+    }
 }
 hipError_t mcn_launch_cap_random(const int2* idx_in, const int* count, int max_rows, int keep, const unsigned* seed, unsigned* ws,
                                  int2* idx_out, int* count_out, hipStream_t st) {
     if (max_rows <= 0 || keep <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(ws, 0, MCN_CAP_WS * sizeof(unsigned), st);
     if (e != hipSuccess) return e;
-    const int blocks = min((max_rows + 255) / 256, 2048);
+    const int blocks = min((max_rows + 255) / 256, MCN_CAP_BLOCKS);
     hipLaunchKernelGGL(cap_hist_hi_kernel, dim3(blocks), dim3(256), 0, st, count, max_rows, keep, seed, ws);
     hipLaunchKernelGGL(cap_find_hi_kernel, dim3(1), dim3(1024), 0, st, count, max_rows, keep, ws);
     hipLaunchKernelGGL(cap_hist_lo_kernel, dim3(blocks), dim3(256), 0, st, count, max_rows, keep, seed, ws);
     hipLaunchKernelGGL(cap_find_lo_kernel, dim3(1), dim3(1024), 0, st, count, max_rows, keep, ws);
+    hipLaunchKernelGGL(cap_count_kernel, dim3(blocks), dim3(256), 0, st, count, max_rows, keep, seed, ws);
     hipLaunchKernelGGL(cap_write_kernel, dim3(blocks), dim3(256), 0, st, idx_in, count, max_rows, keep, seed, ws, idx_out, count_out);
     return hipGetLastError();
 }

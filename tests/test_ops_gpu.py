@@ -473,6 +473,7 @@ def test_cap_random_device_side(gpu_device):
         assert int(c2.item()) == keep
         flat = idx2[:, 0].long() * 97 + idx2[:, 1].long()
         assert int(flat.max()) < K and torch.unique(flat).numel() == keep            # a subset of the valid entries, no duplicates
+        assert bool((flat[1:] > flat[:-1]).all())                                     # ... in the order of the list
         hits[flat] += 1
     # every entry is kept with probability keep / K = 0.4: the per-entry hit count is Binomial(64, 0.4)
     mean = float(hits.mean()) / trials
@@ -480,19 +481,22 @@ def test_cap_random_device_side(gpu_device):
     assert float(hits.max()) <= 48 and float(hits.min()) >= 6                        # ~ +-5.7 sigma
     halves = hits[: K // 2].mean() / hits[K // 2:].mean()
     assert abs(float(halves) - 1.0) < 0.01                                           # no positional bias
-    # same seed -> same subset (as a set)
+    # same seed -> the same list, entry for entry (no atomic decides a position)
     seed = torch.tensor([42], dtype=torch.int32, device=dev)
     a, _ = ops.cap_random(idx, count, cap, keep, seed)
-    b, _ = ops.cap_random(idx, count, cap, keep, seed)
-    sa = torch.sort(a[:, 0].long() * 97 + a[:, 1].long()).values
-    sb = torch.sort(b[:, 0].long() * 97 + b[:, 1].long()).values
-    assert torch.equal(sa, sb)
-    # cap not binding: the first *count entries, all of them
-    small = torch.tensor([1500], dtype=torch.int32, device=dev)
-    idx3, c3 = ops.cap_random(idx, small, cap, keep, seed)
-    assert int(c3.item()) == 1500
-    got = torch.sort(idx3[:1500, 0].long() * 97 + idx3[:1500, 1].long()).values
-    assert torch.equal(got, torch.arange(1500, device=dev))
+    for _ in range(3):
+        b, _ = ops.cap_random(idx, count, cap, keep, seed)
+        assert torch.equal(a, b)
+    # cap not binding: the first *count entries as they stand (the reference's order, model/mc_nerf.py:625-632)
+    for n_small in (1500, 1, keep):
+        small = torch.tensor([n_small], dtype=torch.int32, device=dev)
+        idx3, c3 = ops.cap_random(idx, small, cap, keep, seed)
+        assert int(c3.item()) == n_small and torch.equal(idx3[:n_small], idx[:n_small])
+    # one more than fits: exactly one entry dropped, the rest in order
+    over = torch.tensor([keep + 1], dtype=torch.int32, device=dev)
+    idx4, c4 = ops.cap_random(idx, over, cap, keep, seed)
+    f4 = idx4[:, 0].long() * 97 + idx4[:, 1].long()
+    assert int(c4.item()) == keep and int(f4.max()) <= keep and bool((f4[1:] > f4[:-1]).all())
 
 
 def test_sample_perm_is_a_random_subset_without_replacement(gpu_device):
