@@ -134,10 +134,12 @@ def test_composite_fwd_bwd(gpu_device, S):
 def test_select_fine(gpu_device):
     ops = _ops()
     dev = gpu_device
-    for N, Sc, scale, seed in [(70, 64, 2, 0), (33, 32, 5, 1), (5, 128, 5, 2)]:
+    # (the scan gives every thread a run of a multiple of four rays: sizes around the run boundaries, a ragged tail, one ray,
+    #  and more than 65536 rays -- the scalar path)
+    for N, Sc, scale, seed in [(70, 64, 2, 0), (33, 32, 5, 1), (5, 128, 5, 2), (1, 16, 3, 3), (4097, 16, 2, 4), (7000, 64, 2, 5), (32768, 16, 1, 6), (70001, 8, 2, 7)]:
         g = torch.Generator().manual_seed(seed)
         w = torch.rand(N, Sc, generator=g) * 4e-3
-        w[1] = 0.0
+        w[N // 2] = 0.0 if N > 1 else w[0]
         cfg = O.RenderCfg(samples=Sc, scale=scale)
         ref = O.select_fine(w, cfg)
         wmax = w.max().reshape(1).view(torch.int32).to(dev)
