@@ -22,8 +22,10 @@
  *     bits 4..6 (`MLP_deg` 0 .. 3, model/net_block.py:43, 75-76; 3 (deg + 1)^2 sh.2 outputs; default 2), and in
  *     bits 0..3 the number of encoding frequencies + 1 (`emb_freqs_xyz` 0 .. 10, model/net_block.py:11-18:
  *     3 + 6 F encoded channels; 0 = the default 10).  The exact-fp32 entry points take any mask, degree and
- *     frequency count, the `_16` entry points (f16 / bf16 / f16x3 register chains) at most one skip layer,
- *     degree 2 and 10 frequencies;
+ *     frequency count, the `_16` entry points (f16 / bf16 / f16x3 register chains) at most one skip layer and
+ *     degrees 0 .. 2 (any frequency count: their kernels have the geometry of degree 2 and 10 frequencies; a smaller
+ *     net's tensors are scattered into it by mcnerf_pack_weights_16 -- zero weights where it has no channel / row --
+ *     and its weight gradients gathered back by mcnerf_mlp_dw_16; `barf_w` is always 10 values there);
  *   - parameters of one net live in ONE flat fp32 buffer in the reference's state-dict order
  *     (xyz_encoding_{1..depth}.0.{weight,bias}, sigma.0.*, sigma.2.*, sh.0.*, sh.2.*), Linear weights
  *     [out][in] row-major; gradients use the same layout.

@@ -29,9 +29,10 @@ static bool net_ok(int depth, int width, int skip) {
     if (skip >= MCN_SKIP_MASK && ((skip >> 8) >> depth) != 0) return false;          // -1, a layer index, or a mask of layers < depth
     return mcn_topo_deg(skip) <= MCN_MAXDEG && mcn_topo_nfreq(skip) <= MCN_NFREQ;
 }
-// the register-chain families (f16 / bf16 / f16x3) take at most one skip layer, SH degree 2 and 10 encoding frequencies
+// the register-chain families (f16 / bf16 / f16x3) take at most one skip layer and SH degrees 0 .. 2 (their kernels have the geometry
+// of degree 2 and 10 frequencies; a smaller net is scattered into it when its weights are packed: mcnerf_common.h)
 static bool net16_ok(int depth, int width, int skip) {
-    return net_ok(depth, width, skip) && mcn_single_skip(mcn_skip_mask(depth, skip)) != -2 && mcn_topo_deg(skip) == 2 && mcn_topo_nfreq(skip) == MCN_NFREQ;
+    return net_ok(depth, width, skip) && mcn_single_skip(mcn_skip_mask(depth, skip)) != -2 && mcn_topo_deg(skip) <= 2;
 }
 #define REQ(cond, name) do { if (!(cond)) return fail(name, "invalid argument: " #cond); } while (0)
 

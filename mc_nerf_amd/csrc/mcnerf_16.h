@@ -38,7 +38,11 @@
 //   forward    : fragment (tile t, step s), lane (i, h), element j = src[(32 t + i) * ld + col0 + c(s,h,j)]
 //   transposed : ............................................... = src[c(s,h,j) * ld + col0 + 32 t + i]
 // out_real = valid outputs (rows of the fragment tile), con_real = valid extent of the contraction index.
-struct Mcn16Part { int src, ld, col0, out_real, con_real, ksteps; };
+// map: 0 = indices as they are; 1 .. 10 = the part's ENCODED-channel index (the contraction index, or the output index of a
+// transposed part) goes through mcn_enc_col(., map); 16 + deg = its sh.2-row index (the output index, or the contraction index of a
+// transposed part) through mcn_sh_row(., deg) -- nets with fewer than 10 frequencies / an SH degree below 2 (mcnerf_common.h).
+struct Mcn16Part { int src, ld, col0, out_real, con_real, ksteps, map; };
+static inline __host__ __device__ int mcn16_map_enc(int map) { return map >= 1 && map <= MCN_NFREQ; }
 struct Mcn16Seg { int first_frag, tiles, transposed; Mcn16Part a, b; };   // per tile: a.ksteps fragments of part a, then b.ksteps of part b
 #define MCN16_MAXSEG 24
 struct Mcn16Stream { int nseg, total_frags; Mcn16Seg seg[MCN16_MAXSEG]; };
@@ -55,16 +59,17 @@ static inline void mcn16_add(Mcn16Stream& st, int tiles, int transposed, Mcn16Pa
 static inline Mcn16Stream mcn16_fwd_stream(const McnLayout& L) {
     Mcn16Stream st; st.nseg = 0; st.total_frags = 0;
     const int W = L.width, NT = W / 32, KS = W / 16;
-    const Mcn16Part none = {0, 0, 0, 0, 0, 0};
-    mcn16_add(st, NT, 0, Mcn16Part{L.pW[0], MCN_ENC, 0, W, MCN_ENC, MCN16_ENCKS}, none);
+    const int ME = L.nfreq == MCN_NFREQ ? 0 : L.nfreq, MS = L.sh_deg == 2 ? 0 : 16 + L.sh_deg;      // (index maps: see Mcn16Part)
+    const Mcn16Part none = {0, 0, 0, 0, 0, 0, 0};
+    mcn16_add(st, NT, 0, Mcn16Part{L.pW[0], L.nenc, 0, W, MCN_ENC, MCN16_ENCKS, ME}, none);
     for (int l = 1; l < L.depth; ++l) {
-        if (l == L.skip) mcn16_add(st, NT, 0, Mcn16Part{L.pW[l], W + MCN_ENC, 0, W, MCN_ENC, MCN16_ENCKS},
-                                   Mcn16Part{L.pW[l], W + MCN_ENC, MCN_ENC, W, W, KS});
-        else mcn16_add(st, NT, 0, Mcn16Part{L.pW[l], W, 0, W, W, KS}, none);
+        if (l == L.skip) mcn16_add(st, NT, 0, Mcn16Part{L.pW[l], W + L.nenc, 0, W, MCN_ENC, MCN16_ENCKS, ME},
+                                   Mcn16Part{L.pW[l], W + L.nenc, L.nenc, W, W, KS, 0});
+        else mcn16_add(st, NT, 0, Mcn16Part{L.pW[l], W, 0, W, W, KS, 0}, none);
     }
-    mcn16_add(st, NT, 0, Mcn16Part{L.pWs1, W, 0, W, W, KS}, none);
-    mcn16_add(st, NT, 0, Mcn16Part{L.pWc1, W, 0, W, W, KS}, none);
-    mcn16_add(st, 1, 0, Mcn16Part{L.pWc2, W, 0, MCN_NSH, W, KS}, none);
+    mcn16_add(st, NT, 0, Mcn16Part{L.pWs1, W, 0, W, W, KS, 0}, none);
+    mcn16_add(st, NT, 0, Mcn16Part{L.pWc1, W, 0, W, W, KS, 0}, none);
+    mcn16_add(st, 1, 0, Mcn16Part{L.pWc2, W, 0, MCN_NSH, W, KS, MS}, none);
     return st;
 }
 // Backward stream (dX = W^T dY, consumption order of mlp16_bwd.hip): sigma.0^T, sh.2^T, sh.0^T, then for l = D-1 .. 1
@@ -72,16 +77,17 @@ static inline Mcn16Stream mcn16_fwd_stream(const McnLayout& L) {
 static inline Mcn16Stream mcn16_bwd_stream(const McnLayout& L) {
     Mcn16Stream st; st.nseg = 0; st.total_frags = 0;
     const int W = L.width, NT = W / 32, KS = W / 16;
-    const Mcn16Part none = {0, 0, 0, 0, 0, 0};
-    mcn16_add(st, NT, 1, Mcn16Part{L.pWs1, W, 0, W, W, KS}, none);
-    mcn16_add(st, NT, 1, Mcn16Part{L.pWc2, W, 0, W, MCN_NSH, 2}, none);
-    mcn16_add(st, NT, 1, Mcn16Part{L.pWc1, W, 0, W, W, KS}, none);
+    const int ME = L.nfreq == MCN_NFREQ ? 0 : L.nfreq, MS = L.sh_deg == 2 ? 0 : 16 + L.sh_deg;
+    const Mcn16Part none = {0, 0, 0, 0, 0, 0, 0};
+    mcn16_add(st, NT, 1, Mcn16Part{L.pWs1, W, 0, W, W, KS, 0}, none);
+    mcn16_add(st, NT, 1, Mcn16Part{L.pWc2, W, 0, W, MCN_NSH, 2, MS}, none);
+    mcn16_add(st, NT, 1, Mcn16Part{L.pWc1, W, 0, W, W, KS, 0}, none);
     for (int l = L.depth - 1; l >= 1; --l) {
-        const int ld = (l == L.skip) ? W + MCN_ENC : W;
-        if (l == L.skip) mcn16_add(st, 2, 1, Mcn16Part{L.pW[l], ld, 0, MCN_ENC, W, KS}, none);
-        mcn16_add(st, NT, 1, Mcn16Part{L.pW[l], ld, (l == L.skip) ? MCN_ENC : 0, W, W, KS}, none);
+        const int ld = (l == L.skip) ? W + L.nenc : W;
+        if (l == L.skip) mcn16_add(st, 2, 1, Mcn16Part{L.pW[l], ld, 0, MCN_ENC, W, KS, ME}, none);
+        mcn16_add(st, NT, 1, Mcn16Part{L.pW[l], ld, (l == L.skip) ? L.nenc : 0, W, W, KS, 0}, none);
     }
-    mcn16_add(st, 2, 1, Mcn16Part{L.pW[0], MCN_ENC, 0, MCN_ENC, W, KS}, none);
+    mcn16_add(st, 2, 1, Mcn16Part{L.pW[0], L.nenc, 0, MCN_ENC, W, KS, ME}, none);
     return st;
 }
 

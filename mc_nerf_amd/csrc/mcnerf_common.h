@@ -32,17 +32,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (model/net_block.py:55-58, 71), >= MCN_SKIP_MASK = (bit mask of such layers) << 8 -- the reference's `skips` is a list.
 // The exact-fp32 kernel family handles any mask; the register-chain families (f16 / bf16 / f16x3) one skip layer.
 // In the mask form the low byte may also carry the SH degree of the colour head (`MLP_deg`, model/net_block.py:43, 75-76):
-// bit 7 set -> bits 4..6 = degree (0 .. 3); otherwise (and in the index forms) the degree is 2.  Degrees other than 2: exact-fp32
+// bit 7 set -> bits 4..6 = degree (0 .. 3); otherwise (and in the index forms) the degree is 2.  Degree 3: exact-fp32
 // family only.
 #define MCN_SKIP_MASK 256
 #define MCN_TOPO_HAS_DEG 0x80
 static inline int mcn_topo_deg(int skip) { return (skip >= MCN_SKIP_MASK && (skip & MCN_TOPO_HAS_DEG)) ? ((skip >> 4) & 7) : 2; }
 // ... and in bits 0..3 the number of encoding frequencies + 1 (`emb_freqs_xyz`, model/net_block.py:11-18: 3 + 6 F input channels;
-// 0 = the default 10).  F <= 10 (the 64-column encoded-input tiles of every kernel); F != 10: exact-fp32 family only.
+// 0 = the default 10).  F <= 10 (the 64-column encoded-input tiles of every kernel).
 static inline int mcn_topo_nfreq(int skip) { return (skip >= MCN_SKIP_MASK && (skip & 15)) ? (skip & 15) - 1 : MCN_NFREQ; }
 static inline unsigned mcn_skip_mask(int depth, int skip) {
     if (skip >= MCN_SKIP_MASK) return ((unsigned)skip >> 8) & ((1u << depth) - 1u) & ~1u;      // (layer 0 takes the encoding alone)
     return (skip > 0 && skip < depth) ? (1u << skip) : 0u;
+}
+// Index maps of the register-chain families, whose kernels have ONE geometry (10 frequencies = 63 encoded channels, SH degree 2 =
+// 27 sh.2 rows): a net with F < 10 frequencies / a degree below 2 runs on it with its tensors scattered into that geometry -- the
+// channels / rows it does not have carry zero weights (and a zero bias), so they contribute nothing forward or backward, and
+// their weight gradients are dropped.  -> the column (row) of the net's own tensor, -1 = none.
+//   encoded channel order (model/net_block.py:20-35): [x, y, z, per axis: sin 2^0 .. 2^(F-1), cos 2^0 .. 2^(F-1)]
+static inline __host__ __device__ int mcn_enc_col(int c, int F) {
+    if (F == MCN_NFREQ || c < 3) return c;
+    const int a = (c - 3) / (2 * MCN_NFREQ), r = (c - 3) % (2 * MCN_NFREQ), sc = r / MCN_NFREQ, k = r % MCN_NFREQ;
+    return k < F ? 3 + a * 2 * F + sc * F + k : -1;
+}
+//   sh.2 rows: colour-major, (deg + 1)^2 coefficients per colour (model/net_block.py:75)
+static inline __host__ __device__ int mcn_sh_row(int n, int deg) {
+    if (deg == 2) return n;
+    const int nb = (deg + 1) * (deg + 1), c = n / 9, i = n % 9;
+    return i < nb ? c * nb + i : -1;
 }
 // the one skip layer of a mask, -1 for none, -2 for more than one
 static inline int mcn_single_skip(unsigned mask) {

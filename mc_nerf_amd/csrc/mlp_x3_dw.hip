@@ -21,6 +21,8 @@ struct DwX3Seg {
     int col2, k_real2;            // input K + k of X2: column col2 + k, real for k < k_real2
     float* dW; int ldw;
     float* db;
+    int kmap, kmap2, nmap;        // index maps (mcnerf_common.h; 0 = none): encoded input columns of X / X2 through mcn_enc_col(k, F = kmap / kmap2),
+                                  // sh.2 output rows through mcn_sh_row(n, nmap - 16): gradients of channels / rows the net does not have are dropped
 };
 
 constexpr int dwx3_pick(int N, int K, bool want_vn) {
@@ -227,26 +229,55 @@ __device__ __forceinline__ void dwx3_run(const DwX3Seg& sg, const int t0, const 
     // ---- accumulators -> global (float atomics; one register = two 128-byte row segments)
     const int r = lane & 31, h = lane >> 5;
     const float inv = 1.0f / (sgs * MCNX3_SX), inv_b = 1.0f / sgs;
+    if (!(sg.kmap | sg.kmap2 | sg.nmap)) {
 #pragma unroll
-    for (int t = 0; t < VN; ++t)
+        for (int t = 0; t < VN; ++t)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const int k = kbase + 32 * kt + r;
-            const bool in2 = K2 > 0 && kbase + 32 * kt >= K1;
-            const bool k_ok = in2 ? (k - K1 < sg.k_real2) : (k < sg.k_real);
-            const int colk = in2 ? sg.col2 + (k - K1) : sg.col + k;
+            for (int kt = 0; kt < KT; ++kt) {
+                const int k = kbase + 32 * kt + r;
+                const bool in2 = K2 > 0 && kbase + 32 * kt >= K1;
+                const bool k_ok = in2 ? (k - K1 < sg.k_real2) : (k < sg.k_real);
+                const int colk = in2 ? sg.col2 + (k - K1) : sg.col + k;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (n >= sg.n_lo && n < sg.n_real && k_ok) atomicAdd(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + colk, acc[t][kt][e] * inv);
+                for (int e = 0; e < 16; ++e) {
+                    const int n = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (n >= sg.n_lo && n < sg.n_real && k_ok) atomicAdd(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + colk, acc[t][kt][e] * inv);
+                }
+            }
+        if (bias) {
+#pragma unroll
+            for (int t = 0; t < VN; ++t) {
+                const float b = (bsum[t] + __shfl_xor(bsum[t], 32)) * inv_b;
+                const int n = nbase + 32 * t + r;
+                if (h == 0 && n >= sg.n_lo && n < sg.n_real) atomicAdd(sg.db + (n - sg.n_lo), b);
             }
         }
-    if (bias) {
+    } else {      // a net scattered into the kernel geometry (fewer frequencies / a lower SH degree: mcnerf_common.h): its own columns / rows
 #pragma unroll
-        for (int t = 0; t < VN; ++t) {
-            const float b = (bsum[t] + __shfl_xor(bsum[t], 32)) * inv_b;
-            const int n = nbase + 32 * t + r;
-            if (h == 0 && n >= sg.n_lo && n < sg.n_real) atomicAdd(sg.db + (n - sg.n_lo), b);
+        for (int t = 0; t < VN; ++t)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int k = kbase + 32 * kt + r;
+                const bool in2 = K2 > 0 && kbase + 32 * kt >= K1;
+                const int kk = in2 ? k - K1 : k, km = in2 ? sg.kmap2 : sg.kmap;
+                const int kc = km ? mcn_enc_col(kk, km) : kk;         // (a net with fewer encoding frequencies: its own column, or none)
+                const bool k_ok = kk < (in2 ? sg.k_real2 : sg.k_real) && kc >= 0;
+                const int colk = (in2 ? sg.col2 : sg.col) + kc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int nr = sg.nmap ? mcn_sh_row(n - sg.n_lo, sg.nmap - 16) : n - sg.n_lo;      // (an SH degree below 2: its own row, or none)
+                    if (n >= sg.n_lo && n < sg.n_real && k_ok && nr >= 0) atomicAdd(sg.dW + (size_t)nr * sg.ldw + colk, acc[t][kt][e] * inv);
+                }
+            }
+        if (bias) {
+#pragma unroll
+            for (int t = 0; t < VN; ++t) {
+                const float b = (bsum[t] + __shfl_xor(bsum[t], 32)) * inv_b;
+                const int n = nbase + 32 * t + r;
+                const int nr = sg.nmap ? mcn_sh_row(n - sg.n_lo, sg.nmap - 16) : n - sg.n_lo;
+                if (h == 0 && n >= sg.n_lo && n < sg.n_real && nr >= 0) atomicAdd(sg.db + nr, b);
+            }
         }
     }
 }
@@ -328,6 +359,7 @@ static hipError_t dwx3_launch_job(const DwX3Job& job, const int* count, int rows
 hipError_t mcnx3_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
     const McnLayout& L = a.lay;
     const int W = L.width, D = L.depth, KS = W / 16;
+    const int ME = L.nfreq == MCN_NFREQ ? 0 : L.nfreq, MS = L.sh_deg == 2 ? 0 : 16 + L.sh_deg;      // index maps (DwX3Seg)
     auto act = [&](int slot) { return reinterpret_cast<const char*>(a.act_ws) + (size_t)slot * a.slot_bytes; };
     auto dy = [&](int slot) { return reinterpret_cast<const char*>(a.dy_ws) + (size_t)slot * a.slot_bytes; };
     const char* enc = reinterpret_cast<const char*>(a.enc_ws);
@@ -342,20 +374,20 @@ hipError_t mcnx3_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
         float* dWl = a.grads + L.pW[l];
         float* dbl = a.grads + L.pB[l];
         if (l == 0)                       // encoded-input columns only
-            add(1, DwX3Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl});
+            add(1, DwX3Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl, ME, 0, 0});
         else if (l == L.skip && merged)   // [hidden | encoded] in one pass: hidden k -> column 63 + k, encoded k -> column k
-            add(3, DwX3Seg{dy(l), KS, act(l - 1), KS, enc, MCN16_ENCKS, 0, W, MCN_ENC, W, 0, MCN_ENC, dWl, ldw, dbl});
+            add(3, DwX3Seg{dy(l), KS, act(l - 1), KS, enc, MCN16_ENCKS, 0, W, L.nenc, W, 0, MCN_ENC, dWl, ldw, dbl, 0, ME, 0});
         else if (l == L.skip) {
-            add(1, DwX3Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl});
-            add(0, DwX3Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, MCN_ENC, W, 0, 0, dWl, ldw, nullptr});
+            add(1, DwX3Seg{dy(l), KS, enc, MCN16_ENCKS, nullptr, 0, 0, W, 0, MCN_ENC, 0, 0, dWl, ldw, dbl, ME, 0, 0});
+            add(0, DwX3Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, L.nenc, W, 0, 0, dWl, ldw, nullptr, 0, 0, 0});
         } else
-            add(0, DwX3Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, dWl, ldw, dbl});
+            add(0, DwX3Seg{dy(l), KS, act(l - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, dWl, ldw, dbl, 0, 0, 0});
     }
-    add(0, DwX3Seg{dy(D), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWs1, W, a.grads + L.pBs1});
-    add(0, DwX3Seg{dy(D + 1), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWc1, W, a.grads + L.pBc1});
-    add(2, DwX3Seg{dsh, 2, act(D + 1), KS, nullptr, 0, 0, MCN_NSH, 0, W, 0, 0, a.grads + L.pWc2, W, a.grads + L.pBc2});
+    add(0, DwX3Seg{dy(D), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWs1, W, a.grads + L.pBs1, 0, 0, 0});
+    add(0, DwX3Seg{dy(D + 1), KS, act(D - 1), KS, nullptr, 0, 0, W, 0, W, 0, 0, a.grads + L.pWc1, W, a.grads + L.pBc1, 0, 0, 0});
+    add(2, DwX3Seg{dsh, 2, act(D + 1), KS, nullptr, 0, 0, MCN_NSH, 0, W, 0, 0, a.grads + L.pWc2, W, a.grads + L.pBc2, 0, 0, MS});
     // sigma.2 (1 x W): d sigma sits in column 27 of dsh, its input is the sigma hidden layer
-    add(2, DwX3Seg{dsh, 2, act(D), KS, nullptr, 0, MCN_NSH, MCN_NSH + 1, 0, W, 0, 0, a.grads + L.pWs2, W, a.grads + L.pBs2});
+    add(2, DwX3Seg{dsh, 2, act(D), KS, nullptr, 0, MCN_NSH, MCN_NSH + 1, 0, W, 0, 0, a.grads + L.pWs2, W, a.grads + L.pBs2, 0, 0, 0});
     switch (W) {
         case 256: return dwx3_launch_job<256>(job, a.count, a.rows, a.gmax_bits, st);
         case 128: return dwx3_launch_job<128>(job, a.count, a.rows, a.gmax_bits, st);

@@ -195,7 +195,10 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         sbias[(D + 1) * W + i] = a.params[a.lay.pBc1 + i] * SXW;
         sw2[i] = a.params[a.lay.pWs2 + i];
     }
-    if (tid < 32) sbc2[tid] = tid < MCN_NSH ? a.params[a.lay.pBc2 + tid] * SXW : 0.f;
+    if (tid < 32) {      // sh.2 bias in the kernel's 27-row geometry (a degree below 2: the rows the net has, zero elsewhere)
+        const int row = tid < MCN_NSH ? mcn_sh_row(tid, a.lay.sh_deg) : -1;
+        sbc2[tid] = row >= 0 ? a.params[a.lay.pBc2 + row] * SXW : 0.f;
+    }
     const float bs2 = a.params[a.lay.pBs2];
     float bw[MCN_NFREQ];
 #pragma unroll

@@ -15,6 +15,16 @@ __device__ __forceinline__ void mcn16_range_watch(const float (&v)[8], float lim
     if (!(m <= limit)) atomicOr(flags + seg, 1u);
 }
 
+// element (output o, contraction index c) of a part in the kernels' geometry <- the net's own tensor (index maps: Mcn16Part)
+__device__ __forceinline__ float mcn16_pack_src(const float* __restrict__ params, const Mcn16Part& p, int transposed, int o, int c) {
+    if (p.map) {
+        if (mcn16_map_enc(p.map)) { if (transposed) o = mcn_enc_col(o, p.map); else c = mcn_enc_col(c, p.map); }
+        else { if (transposed) c = mcn_sh_row(c, p.map - 16); else o = mcn_sh_row(o, p.map - 16); }
+        if (o < 0 || c < 0) return 0.f;
+    }
+    return transposed ? params[p.src + (size_t)c * p.ld + p.col0 + o] : params[p.src + (size_t)o * p.ld + p.col0 + c];
+}
+
 template <bool BF>
 __global__ void pack16_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __restrict__ params, char* __restrict__ pf, char* __restrict__ pb, unsigned* flags) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,8 +52,7 @@ __global__ void pack16_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = mcn16_chan(kk, h, j);          // contraction index
-            if (o < p.out_real && c < p.con_real)
-                v[j] = sg.transposed ? params[p.src + (size_t)c * p.ld + p.col0 + o] : params[p.src + (size_t)o * p.ld + p.col0 + c];
+            if (o < p.out_real && c < p.con_real) v[j] = mcn16_pack_src(params, p, sg.transposed, o, c);
         }
     }
     if (flags && !bwd) mcn16_range_watch(v, BF ? 3.0e38f : 65504.f, flags, s);
@@ -91,8 +100,7 @@ __global__ void packx3_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = mcn16_chan(kk, h, j);
-            if (o < p.out_real && c < p.con_real)
-                v[j] = sg.transposed ? params[p.src + (size_t)c * p.ld + p.col0 + o] : params[p.src + (size_t)o * p.ld + p.col0 + c];
+            if (o < p.out_real && c < p.con_real) v[j] = mcn16_pack_src(params, p, sg.transposed, o, c);
         }
     }
     if (flags && !bwd) mcn16_range_watch(v, 65504.f / MCNX3_SW, flags, s);

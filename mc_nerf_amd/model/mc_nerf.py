@@ -68,8 +68,8 @@ class NeRF_Model(nn.Module):
         if self.precision not in ops.PRECISIONS:
             raise ValueError(f"precision must be one of {ops.PRECISIONS}")
         if self.precision != "f32" and (self.nerf_coarse.net.fp32_only or self.nerf_fine.net.fp32_only):
-            raise ValueError("a net with more than one skip layer, an SH degree other than 2 or other than 10 encoding frequencies runs in "
-                             f"precision 'f32' only (the register-chain kernels of '{self.precision}' take one skip layer, MLP_deg = 2, emb_freqs_xyz = 10)")
+            raise ValueError("a net with more than one skip layer or SH degree 3 runs in precision 'f32' only "
+                             f"(the register-chain kernels of '{self.precision}' take one skip layer and MLP_deg <= 2)")
         self.settings = RenderSettings(self.samples_c, self.sample_scale, float(self.weight_thresh),
                                        float(self.sigma_default), bool(self.white_back), precision=self.precision)
         self.last_selection = None
@@ -196,7 +196,7 @@ class NeRF_Model(nn.Module):
         st = self.settings
         flat = model.flat_params()
         packed = ops.pack_weights(model.net, flat, precision=st.precision)
-        barf_w = embedding_xyz.barf_weights_on(step_r, dev)
+        barf_w = embedding_xyz.barf_weights_on(step_r, dev, pad=10)
         if idx_render is None:
             out = torch.empty(N, S_, 4, dtype=torch.float32, device=dev)
             ops.mlp_fwd(model.net, flat, packed, rays_o, rays_d, grid, jitter, barf_w, out, precision=st.precision)
@@ -306,7 +306,7 @@ class NeRF_Model(nn.Module):
         if M > 0:
             prepared = (ops.pack_weights(model_coarse.net, model_coarse.flat_params(), precision=prec),
                         ops.pack_weights(model_fine.net, model_fine.flat_params(), precision=prec),
-                        self.emmbedding_xyz.barf_weights_on(1, rays_d.device))
+                        self.emmbedding_xyz.barf_weights_on(1, rays_d.device, pad=10))
         for i in range(0, M, chunk):
             r, d, o = self.render_rays_test(rays_d[i:i + chunk], rays_o[i:i + chunk], model_coarse, model_fine, _prepared=prepared)
             rgb[i:i + chunk], depth[i:i + chunk], opac[i:i + chunk] = r, d, o

@@ -94,10 +94,14 @@ class SinCosEmbedding(nn.Module):
         k = torch.arange(L, dtype=torch.float32)
         return (1.0 - torch.cos(torch.clamp(alpha - k, 0.0, 1.0) * math.pi)) / 2.0
 
-    def barf_weights_on(self, step_r, device) -> torch.Tensor:
+    def barf_weights_on(self, step_r, device, pad: int = 0) -> torch.Tensor:
         """``barf_weights`` as a device tensor; on a GPU the ten host values are passed as kernel arguments
-        (``ops.upload_f32``) so the host never blocks on the stream."""
+        (``ops.upload_f32``) so the host never blocks on the stream.  ``pad``: zero-extended to that many values (the fused MLP
+        kernels of the register-chain modes read ten, whatever ``emb_freqs_xyz`` is: a net with fewer frequencies has zero
+        weights on the channels of the others)."""
         w = self.barf_weights(step_r)
+        if pad > w.numel():
+            w = torch.cat([w, torch.zeros(pad - w.numel())])
         return ops.upload_f32(w, device) if torch.device(device).type == "cuda" else w.to(device)
 
     def forward(self, x, step_r):
@@ -133,9 +137,9 @@ class CorseFine_NeRF(nn.Module):
         self.depth = sys_params[f"{key}_MLP_depth"]
         self.width = sys_params[f"{key}_MLP_width"]
         self.skips = list(sys_params[f"{key}_MLP_skip"])
-        # any `skips` list (reference :45, 55-58), SH degree 0 .. 3 (:43, 75-76) and 0 .. 10 encoding frequencies (:11-18); more than one
-        # skip layer, a degree other than 2 or a frequency count other than 10 run on the exact-fp32 kernel family only
-        # (NeRF_Model refuses the register-chain precision modes for such a net)
+        # any `skips` list (reference :45, 55-58), SH degree 0 .. 3 (:43, 75-76) and 1 .. 10 encoding frequencies (:11-18); more than one
+        # skip layer or degree 3 run on the exact-fp32 kernel family only (NeRF_Model refuses the register-chain precision modes
+        # for such a net)
         self.net = ops.Net(self.depth, self.width, ops.skip_code(self.skips, self.depth, self.deg, self.n_freqs))
         for i in range(self.depth):
             fan_in = self.net.in_features(i)

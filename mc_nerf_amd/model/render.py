@@ -122,7 +122,7 @@ class RenderTrainFn(torch.autograd.Function):
         rays_d = rays_d.contiguous()
         rays_o = rays_o.contiguous()
         need_grad = any(ctx.needs_input_grad)
-        barf_w = owner.emmbedding_xyz.barf_weights_on(step_r, dev)
+        barf_w = owner.emmbedding_xyz.barf_weights_on(step_r, dev, pad=10)
         jit = jitter.reshape(-1).contiguous()
 
         # ---- coarse pass (dense [N,Sc] grid)
@@ -227,7 +227,7 @@ def render_test(owner, model_c, model_f, rays_d, rays_o, eps_c, eps_sel, eps_f, 
     if prepared is None:
         prepared = (ops.pack_weights(net_c, flat_c, precision=prec, range_flags=model_c.range_flags(prec, dev)),
                     ops.pack_weights(net_f, flat_f, precision=prec, range_flags=model_f.range_flags(prec, dev)),
-                    owner.emmbedding_xyz.barf_weights_on(1, dev))
+                    owner.emmbedding_xyz.barf_weights_on(1, dev, pad=10))
     packed_c, packed_f, barf_w = prepared
     out_c = torch.empty(N, st.samples_c, 4, dtype=torch.float32, device=dev)
     ops.mlp_fwd(net_c, flat_c, packed_c, rays_o, rays_d, owner.z_vals_c, None, barf_w, out_c, precision=prec)

@@ -80,8 +80,10 @@ class Net:
 
     @property
     def fp32_only(self) -> bool:
-        """Topologies only the exact-fp32 kernel family takes (the register-chain modes: one skip layer, SH degree 2, 10 frequencies)."""
-        return self.multi_skip or self.deg != 2 or self.n_freqs != 10
+        """Topologies only the exact-fp32 kernel family takes: more than one skip layer, SH degree 3.  (The register-chain modes have
+        the geometry of one skip layer, degree 2 and 10 frequencies; a net with fewer frequencies or a lower degree is scattered
+        into it when its weights are packed, csrc/mcnerf_common.h.)"""
+        return self.multi_skip or self.deg > 2
 
     def in_features(self, i: int) -> int:
         if i == 0:

@@ -158,17 +158,36 @@ def test_multi_skip_topology_matches_reference(gpu_device):
             NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision=precision))
 
 
+# general-topology goldens per precision mode: (rgb, ray gradients, floor of the per-tensor parameter-gradient gate, multiple of the
+# reference's own reorder noise on the tensor that is also accepted, whole-gradient gate ||g - ref|| / ||ref|| over all parameters).
+# The tensors that decide the per-tensor gate are the first layers of the fine net (|g| ~ 5e-8 against ~ 1e-4 at the heads): f32
+# measures <= 4e-4 of the tensor's max there, f16x3 <= 3.8e-3 -- while the whole gradient is as close in f16x3 (7e-7) as in f32 (9e-7):
+# the per-tensor figure of those tensors is an absolute floor (2e-10) over a tiny maximum.  The single-pass 16-bit modes are held to
+# the whole-gradient gate (measured f16 2.1e-3, bf16 1.2e-2; per tensor they reach 0.18 on those near-cancelled sums) and their colours
+# to the oracle on the device's own selection (a weight within 16-bit rounding of the threshold flips a sample: bf16, degree 1);
+# what pins the index maps of these modes is test_chain_modes_scatter_smaller_nets_into_their_geometry.
+TOPO_TOL = {"f32": (TOL, 1e-4, 3e-4, 8.0, 1e-5), "f16x3": (TOL, 1e-4, 1.5e-2, 8.0, 1e-5), "f16": (1e-4, 1e-1, None, None, 1e-2), "bf16": (6e-4, 3e-1, None, None, 6e-2)}
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
 @pytest.mark.parametrize("name", ["g7_train_s32x2_deg0", "g7_train_s32x2_deg1", "g7_train_s32x2_deg3", "g7_train_s32x2_freq6_barf"])
-def test_sh_degree_topology_matches_reference(gpu_device, name):
+def test_sh_degree_topology_matches_reference(gpu_device, name, precision):
     """General topology: `MLP_deg` 0, 1, 3 (model/net_block.py:43, 75-76; eval_sh up to degree 3, model/net_utils.py:103-179): 3, 12, 48
     sh.2 outputs; and `emb_freqs_xyz` = 6 (39 encoded channels, :11-18) with the BARF mask on and degree 1.  Train render + backward
     against the goldens captured from the actual reference on the exact-fp32 kernel family (SH head templated per degree, degree 3
     as two 32-row tiles of sh.2; the encoding with its real channels packed in front of zero columns), incl. the view-direction
-    gradient through the basis derivatives; the register-chain precision modes refuse the nets."""
+    gradient through the basis derivatives.  The register-chain precision modes run degrees 0 ... 2 and any frequency count on their
+    one kernel geometry (degree 2, 10 frequencies): the net's tensors are scattered into it when the weights are packed, the channels /
+    rows it does not have carry zeros and their weight gradients are dropped (csrc/mcnerf_common.h); degree 3 they refuse."""
     from mc_nerf_amd.model import MC_NeRF_Loss, NeRF_Model
     g = load_golden(name)
     dev = gpu_device
-    m, cfg, pc, pf = build_model(g, dev, precision="f32")
+    if precision != "f32" and int(g["deg"]) == 3:
+        with pytest.raises(ValueError, match="SH degree 3"):
+            build_model(g, dev, precision=precision)
+        return
+    tol_rgb, tol_ray, tol_par, k_noise, tol_all = TOPO_TOL[precision]
+    m, cfg, pc, pf = build_model(g, dev, precision=precision)
     deg = cfg.deg
     n_sh = 3 * (deg + 1) ** 2
     assert m.nerf_fine.sh[2].weight.shape == (n_sh, 64) and m.nerf_fine.net.deg == deg
@@ -177,19 +196,32 @@ def test_sh_degree_topology_matches_reference(gpu_device, name):
     o = t(g["rays_o"]).to(dev).requires_grad_(True)
     rgb_c, rgb_f = m.render_rays_train(d, o, 0, float(g["step_r"]), jitter=t(g["jitter"]).to(dev), eps_c=t(g["eps_c"]).to(dev),
                                        eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
-    assert err(rgb_c, g["rgb_c"]) < TOL and err(rgb_f, g["rgb_f"]) < TOL
+    if precision in ("f32", "f16x3"):
+        assert err(rgb_c, g["rgb_c"]) < tol_rgb and err(rgb_f, g["rgb_f"]) < tol_rgb
+    else:
+        k = int(m.last_selection[1].item())
+        with torch.no_grad():
+            r = O.render_rays_train(pc, pf, cfg, t(g["rays_d"]), t(g["rays_o"]), float(g["step_r"]), t(g["jitter"]), t(g["eps_c"]), t(g["eps_sel"]), t(g["eps_f"]),
+                                    idx_override=m.last_selection[0][:k].cpu().long())
+            k_ref = int(O.render_rays_train(pc, pf, cfg, t(g["rays_d"]), t(g["rays_o"]), float(g["step_r"]), t(g["jitter"]), t(g["eps_c"]), t(g["eps_sel"]),
+                                            t(g["eps_f"]))["idx_f"].shape[0])
+        assert abs(k - k_ref) <= max(2, k_ref // 200)
+        assert err(rgb_c, r["rgb_c"]) < tol_rgb and err(rgb_f, r["rgb_f"]) < tol_rgb
     loss = MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([rgb_c, rgb_f, t(g["gt"]).to(dev)])
-    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    assert abs(float(loss.detach()) - float(g["loss"])) < (1e-5 if precision in ("f32", "f16x3") else 1e-3)
     loss.backward()
     e_d = err(d.grad, g["d_rays_d"]) / float(np.abs(g["d_rays_d"]).max())
     e_o = err(o.grad, g["d_rays_o"]) / float(np.abs(g["d_rays_o"]).max())
-    assert e_d < 1e-4 and e_o < 1e-4, (e_d, e_o)
+    assert e_d < tol_ray and e_o < tol_ray, (e_d, e_o)
     worst = 0.0
     noise = _oracle_reorder_noise(g, cfg)
+    num = den = 0.0
     for tag, net in (("c", m.nerf_coarse), ("f", m.nerf_fine)):
         for k_, p in net.named_parameters():
             ref = g[f"g{tag}.{k_}"] if f"g{tag}.{k_}" in g else g[f"gsamp{tag}.{k_}"]
             got = p.grad if f"g{tag}.{k_}" in g else p.grad.reshape(-1)[::97]
+            num += float(((got.detach().cpu().double() - torch.from_numpy(np.asarray(ref)).double()) ** 2).sum())
+            den += float((torch.from_numpy(np.asarray(ref)).double() ** 2).sum())
             scale = float(np.abs(ref).max())
             if k_.endswith(".bias"):             # (a bias gradient is a plain sum over the samples -- sigma.2's a single number: its
                 wk = k_[:-4] + "weight"          #  cancellation is measured against the layer's weight gradient as well)
@@ -200,16 +232,19 @@ def test_sh_degree_topology_matches_reference(gpu_device, name):
             # 3e-4 of the tensor's scale (measured <= 1.5e-4: sigma.0 of the fine net at degree 3, a tensor the SH head does not
             # touch -- one ReLU decision), or 8 x what the reference arithmetic itself does to this tensor under a re-ordering of the
             # hidden units (degree 0: the coarse sigma gradients nearly cancel -- |d b_sigma2| = 6e-7 -- and that noise alone is 1.1e-4)
-            assert e < max(3e-4, 8.0 * noise[f"{tag}.{k_}"]), (tag, k_, e, noise[f"{tag}.{k_}"])
-    print(f"MLP_deg = {deg} ({n_sh} sh.2 outputs), emb_freqs_xyz = {cfg.n_freqs} vs the reference's golden: rgb {max(err(rgb_c, g['rgb_c']), err(rgb_f, g['rgb_f'])):.1e}, "
+            if tol_par is not None:
+                assert e < max(tol_par, k_noise * noise[f"{tag}.{k_}"]), (tag, k_, e, noise[f"{tag}.{k_}"])
+    e_all = (num / den) ** 0.5
+    assert e_all < tol_all, e_all
+    print(f"[{precision}] whole gradient {e_all:.1e}; MLP_deg = {deg} ({n_sh} sh.2 outputs), emb_freqs_xyz = {cfg.n_freqs} vs the reference's golden: rgb {max(err(rgb_c, g['rgb_c']), err(rgb_f, g['rgb_f'])):.1e}, "
           f"d_rays_d {e_d:.1e}, worst parameter gradient {worst:.1e} of its tensor's max")
     with torch.no_grad():
         r = O.render_rays_test(pc, pf, cfg, t(g["rays_d"]), t(g["rays_o"]), t(g["eps_c"]), t(g["eps_sel"]), t(g["eps_f"]))
         rgb, depth, opacity = m.render_rays_test(t(g["rays_d"]).to(dev), t(g["rays_o"]).to(dev), m.nerf_coarse, m.nerf_fine,
                                                  eps_c=t(g["eps_c"]).to(dev), eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
-    assert float((rgb.cpu() - r["rgb"]).abs().max()) < TOL
-    with pytest.raises(ValueError, match="SH degree other than 2"):
-        NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision="f16x3"))
+    assert float((rgb.cpu() - r["rgb"]).abs().max()) < tol_rgb
+    if precision != "f32":
+        return
     # the stand-alone module forwards of the same topology (SinCosEmbedding.forward / CorseFine_NeRF.forward, differentiable)
     x = (t(g["rays_o"])[:40] + t(g["rays_d"])[:40] * 2.5).to(dev).requires_grad_(True)
     enc = m.emmbedding_xyz(x, float(g["step_r"]))
@@ -1246,6 +1281,77 @@ def test_standalone_module_forwards_match_reference_modules(gpu_device):
         (eg * we.to(dev)).sum().backward()
         assert float((xg.grad.cpu() - xr.grad).abs().max()) < 1e-4 * max(1.0, float(xr.grad.abs().max()))
     assert not emb(x.to(dev), 0.5).requires_grad                   # nothing requires a gradient: plain inference call
+
+
+def _enc_col(c, F):
+    """csrc/mcnerf_common.h mcn_enc_col: column of the 10-frequency encoding -> column of an F-frequency one (None: no such channel)."""
+    if c < 3:
+        return c
+    a, r = divmod(c - 3, 20)
+    sc, k = divmod(r, 10)
+    return 3 + a * 2 * F + sc * F + k if k < F else None
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16", "bf16"])
+@pytest.mark.parametrize("name", ["g7_train_s32x2_deg0", "g7_train_s32x2_deg1", "g7_train_s32x2_freq6_barf"])
+def test_chain_modes_scatter_smaller_nets_into_their_geometry(gpu_device, name, precision):
+    """The register-chain kernels have ONE geometry (SH degree 2, 10 encoding frequencies).  A net with a lower degree / fewer
+    frequencies is scattered into it when its weights are packed (zero weights on the channels and rows it does not have) and its
+    weight gradients gathered back (csrc/mcnerf_common.h, pack16.hip, mlp*_dw.hip).  Pinned here against the SAME mode on the
+    explicitly zero-padded degree-2 / 10-frequency net: colours bit-identical (the packed streams are), every gradient entry the
+    small net has equal up to the order of the weight-gradient atomics."""
+    from mc_nerf_amd.model import MC_NeRF_Loss, NeRF_Model
+    g = load_golden(name)
+    dev = gpu_device
+    m, cfg, pc, pf = build_model(g, dev, precision=precision)
+    F, deg, nb = cfg.n_freqs, cfg.deg, (cfg.deg + 1) ** 2
+    cfg2 = O.RenderCfg(**{**cfg.__dict__, "deg": 2, "n_freqs": 10})
+    m2 = NeRF_Model(make_sys_param(cfg2, device=str(dev), mode=0, precision=precision)).to(dev)
+    m2.emmbedding_xyz.barf_mode = cfg.barf_mode
+    cols = [(c, _enc_col(c, F)) for c in range(63)]
+    rows = [(9 * c + i, c * nb + i) for c in range(3) for i in range(nb)]
+    for small, big in ((m.nerf_coarse, m2.nerf_coarse), (m.nerf_fine, m2.nerf_fine)):
+        sd, bd = small.state_dict(), {k_: torch.zeros_like(v) for k_, v in big.state_dict().items()}
+        for k_, v in sd.items():
+            if v.dim() == 2 and v.shape[1] in (3 + 6 * F, small.width + 3 + 6 * F) and v.shape[1] != bd[k_].shape[1]:      # encoded input columns (+ hidden)
+                for c10, cf in cols:
+                    if cf is not None:
+                        bd[k_][:, c10] = v[:, cf]
+                if v.shape[1] > 3 + 6 * F:
+                    bd[k_][:, 63:] = v[:, 3 + 6 * F:]
+            elif k_.startswith("sh.2") and deg != 2:
+                for r27, rs in rows:
+                    bd[k_][r27] = v[rs]
+            else:
+                bd[k_].copy_(v)
+        big.load_state_dict(bd)
+    if F != 10:          # the small net's BARF schedule (alpha scales with ITS frequency count), zero-extended: exactly what its kernels are given
+        own = m.emmbedding_xyz.barf_weights
+        m2.emmbedding_xyz.barf_weights = lambda step_r: torch.cat([own(step_r), torch.zeros(10 - F)])
+    kw = dict(jitter=t(g["jitter"]).to(dev), eps_c=t(g["eps_c"]).to(dev), eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
+    out = []
+    for model in (m, m2):
+        d = t(g["rays_d"]).to(dev).requires_grad_(True)
+        o = t(g["rays_o"]).to(dev).requires_grad_(True)
+        rgb_c, rgb_f = model.render_rays_train(d, o, 0, float(g["step_r"]), **kw)
+        MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([rgb_c, rgb_f, t(g["gt"]).to(dev)]).backward()
+        out.append((rgb_c.detach(), rgb_f.detach(), d.grad, o.grad))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert torch.equal(m.last_selection[0][:int(m.last_selection[1])], m2.last_selection[0][:int(m2.last_selection[1])])
+    for a_, b_ in zip(out[0][2:], out[1][2:]):
+        assert float((a_ - b_).abs().max()) <= 1e-5 * float(b_.abs().max())
+    for small, big in ((m.nerf_coarse, m2.nerf_coarse), (m.nerf_fine, m2.nerf_fine)):
+        gb = dict(big.named_parameters())
+        for k_, p in small.named_parameters():
+            G = gb[k_].grad
+            if p.dim() == 2 and p.shape[1] != G.shape[1]:
+                pick = [c10 for c10, cf in cols if cf is not None] + list(range(63, G.shape[1]))
+                G = G[:, pick]
+                assert [cf for _, cf in cols if cf is not None] == list(range(3 + 6 * F))          # (the map is monotone: same order)
+            elif k_.startswith("sh.2") and deg != 2:
+                G = G[[r27 for r27, _ in rows]]
+            assert G.shape == p.grad.shape, k_
+            assert float((G - p.grad).abs().max()) <= 2e-5 * max(float(G.abs().max()), 1e-30), (k_, float((G - p.grad).abs().max()), float(G.abs().max()))
 
 
 @pytest.mark.parametrize("precision,value", [("f16x3", 300.0), ("f16", 7.0e4)])
