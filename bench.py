@@ -13,8 +13,10 @@ all-reduce (N > 1) -> RAdam step.  Inputs are resident in HBM before the timed r
 `--gpus N` with N > 1 and no torchrun environment: this process (which never touches the GPU) starts N fresh rank
 processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and waits for them; under
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks are the given processes.
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement"): the headline precision mode (`--precision`; default the
-fp32-grade split-f16 mode `f16x3`: the reference's arithmetic is fp32) timed for `--steps` steps with nothing but the
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement"): the headline precision mode (`--precision`; default `f16x3h`: the
+split-f16 forward and dX chains of `f16x3` -- 22-bit operands, fp32-grade colours: the reference's arithmetic is fp32 -- with the
+weight gradients taken from the hi planes of the saved operands; `f16x3`, all operands 22-bit, is in `by_precision` beside it;
+DESIGN.md 2 has the parity evidence of both) timed for `--steps` steps with nothing but the
 step itself inside the timed region, the per-kernel HIP-event times from a separate untimed pass right after it, plus
 `by_precision` with the other modes of `--also` timed in the same run (>= 20 steps each).
 """
@@ -62,6 +64,7 @@ BX3 = {"fwd": 10 * 1024 + 256 + 128 + 320 + 16 + 8,
        "bwd": 10 * 1024 + 128 + 320 + 128 + 32 + 8,
        "dw": 2 * (2 * 512 * 8 + (2 * 512 + 128) + (512 + 128) + 2 * (512 + 64))}
 DTYPE_TEXT = {"f32": "f32", "f16x3": "f16x3 (fp32-grade: every operand hi + lo f16 = 22 significand bits, 3 f16 MFMAs per product, fp32 accumulate / bias / epilogues, 4-byte saved operands)",
+              "f16x3h": "f16x3h (forward and dX chains as f16x3: 22-bit operands, 3 f16 MFMAs per product; the WEIGHT-gradient operands are the hi planes only = 11 significand bits, 1 MFMA per product, 2-byte saved operands)",
               "f16": "f16 (single-pass f16 MFMA operands, fp32 accumulate, 2-byte workspaces)",
               "bf16": "bf16 (single-pass bf16 MFMA operands, fp32 accumulate, 2-byte workspaces)"}
 RIG_NAMES = {"ball": "Ball_Lego", "array": "Array_Ficus", "halfball": "HalfBall_Materials", "room": "Room_Statue"}
@@ -403,7 +406,7 @@ def run_precision(precision, args, steps, warmup, rank, world, dev, timer, image
         rec["asymmetric_grad_steps"] = sync.asymmetric_steps()      # ranks disagreeing on which tensors have gradients: must be 0
     # roofline of the fine-net kernels with ALGORITHMIC work per launch over the HIP-event launch time
     mfma_peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
-    contract = B16 if precision in ("f16", "bf16") else (BX3 if precision == "f16x3" else B32)
+    contract = B16 if precision in ("f16", "bf16", "f16x3h") else (BX3 if precision == "f16x3" else B32)
     per_call = {}
     for k in ("fwd", "bwd", "dw"):
         ms = ks.get((k, 256))
@@ -450,8 +453,10 @@ def pmc_traffic(precision, kernel_key):
                      "mlp_dw<256>": "dw16_stream_kernel<256, false>"},
              "bf16": {"mlp_fwd<256>": "mlp16_fwd_kernel<256, true, true>", "mlp_bwd<256>": "mlp16_bwd_kernel<256, true>",
                       "mlp_dw<256>": "dw16_stream_kernel<256, true>"},
-             "f16x3": {"mlp_fwd<256>": "mlp_x3_fwd_kernel<256, true>", "mlp_bwd<256>": "mlp_x3_bwd_kernel<256>",
+             "f16x3": {"mlp_fwd<256>": "mlp_x3_fwd_kernel<256, 1>", "mlp_bwd<256>": "mlp_x3_bwd_kernel<256, false>",
                        "mlp_dw<256>": "dwx3_stream_kernel<256>"},
+             "f16x3h": {"mlp_fwd<256>": "mlp_x3_fwd_kernel<256, 2>", "mlp_bwd<256>": "mlp_x3_bwd_kernel<256, true>",
+                        "mlp_dw<256>": "dw16_stream_kernel<256, false>"},
              "f32": {"mlp_fwd<256>": "mlp_fwd_kernel<256, true>", "mlp_bwd<256>": "mlp_bwd_kernel<256>"}}[precision]
     rec = json.load(open(path))
     if rec.get("csrc_digest") != csrc_digest():
@@ -656,10 +661,11 @@ def main():
                     "`occupancy.sigma_bias_shift`) instead of calibrating")
     ap.add_argument("--no-extra", dest="extra", action="store_false", help="skip extra_lines (8x256 coarse, N = 7000, 128x5, render)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16", "bf16"],
-                    help="MFMA mode of the MLP kernels: split-f16 f16x3 (fp32-grade, the headline: the reference computes in fp32) or "
-                         "exact f32 -- the 1e-4 parity modes; single-pass f16 / bf16 -- 16-bit operand modes with their own stated error")
-    ap.add_argument("--also", default="f16,bf16,f32", help="other precision modes measured in the same run (by_precision)")
+    ap.add_argument("--precision", default="f16x3h", choices=["f32", "f16x3", "f16x3h", "f16", "bf16"],
+                    help="MFMA mode of the MLP kernels: split-f16 f16x3h (the headline: fp32-grade forward and dX chains, weight gradients from "
+                         "the hi operand planes), f16x3 (every operand 22-bit) or exact f32 -- the 1e-4 parity modes; single-pass f16 / bf16 -- "
+                         "16-bit operand modes with their own stated error")
+    ap.add_argument("--also", default="f16x3,f16,bf16,f32", help="other precision modes measured in the same run (by_precision)")
     ap.add_argument("--mode", default="train", choices=["train", "render"])
     ap.add_argument("--selftest", action="store_true", help="rendezvous / launcher check only (no kernels; works on CPU)")
     args = ap.parse_args()

@@ -144,6 +144,13 @@ int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows
  *   2 = f16x3: the fp32-GRADE mode.  Every operand is hi + lo (two f16, 22 significand bits), a product is three f16
  *       MFMAs into one fp32 accumulator (~2^-21 relative product error), saved operands are a hi and a lo plane
  *       (4 bytes per value).  This is the mode that meets the 1e-4 parity bar at 16-bit MFMA rates.
+ *   3 = f16x3h: the forward and the backward (dX) chains of dtype 2, instruction for instruction -- colours, selection and ray
+ *       gradients are bit-identical to dtype 2's -- but only the HI plane of every saved operand is written (in dtype 0's
+ *       workspace layout: 2 bytes per value), and mcnerf_mlp_dw_16 is dtype 0's single-pass f16 kernel on those planes
+ *       (activations carry the chains' 2^3 scale): the weight-gradient operands are rounded to 11 significand bits, everything
+ *       that reaches a colour or a dX stays at 22.  Weight gradients differ from dtype 2's by <= 6e-4 of a tensor's largest
+ *       entry (unbiased rounding of the operands); against the reference's own gradients the two modes measure the same
+ *       (DESIGN.md 2).  Packed weights and the sh.2-output workspace (which 4) as dtype 2, the other workspaces as dtype 0.
  * Same reference code replaced as the fp32 entry points above (model/net_block.py:20-35, 67-78;
  * model/net_utils.py:103-191; model/mc_nerf.py:688-701).
  * Packed weights are two fragment STREAMS (forward order, backward = transposed order); workspaces are

@@ -209,18 +209,21 @@ int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows
 }
 
 
-// ---- register-chain modes: single-pass 16-bit (mcnerf_16.h; dtype 0 = f16, 1 = bf16) and split-f16 "f16x3" (mcnerf_x3.h; dtype 2)
-static bool dtype_ok(int dtype) { return dtype == 0 || dtype == 1 || dtype == 2; }
+// ---- register-chain modes: single-pass 16-bit (mcnerf_16.h; dtype 0 = f16, 1 = bf16), split-f16 "f16x3" (mcnerf_x3.h; dtype 2), and
+//      dtype 3 "f16x3h": the split-f16 forward / backward chains saving only the hi plane of every operand (16-bit workspace layout),
+//      the weight gradient by the single-pass f16 kernel on those planes
+static bool dtype_ok(int dtype) { return dtype >= 0 && dtype <= 3; }
+static bool x3_chain(int dtype) { return dtype == 2 || dtype == 3; }
 long long mcnerf_packed_bytes_16(int depth, int width, int skip, int dtype, int backward) {
     if (!net16_ok(depth, width, skip) || !dtype_ok(dtype)) return -1;
     const McnLayout L = mcn_make_layout(depth, width, skip);
-    if (dtype == 2) return (long long)(backward ? mcnx3_bwd_stream(L) : mcnx3_fwd_stream(L)).total_frags * 2048;
+    if (x3_chain(dtype)) return (long long)(backward ? mcnx3_bwd_stream(L) : mcnx3_fwd_stream(L)).total_frags * 2048;
     return (long long)(backward ? mcn16_bwd_stream(L) : mcn16_fwd_stream(L)).total_frags * 1024;
 }
 int mcnerf_pack_weights_16(int depth, int width, int skip, const float* params, void* packed_fwd, void* packed_bwd,
                            int dtype, uint32_t* range_flags, void* stream) {
     REQ(net16_ok(depth, width, skip) && params && packed_fwd && packed_bwd && dtype_ok(dtype), "mcnerf_pack_weights_16");
-    if (dtype == 2) return check("mcnerf_pack_weights_16", mcnx3_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, range_flags, (hipStream_t)stream));
+    if (x3_chain(dtype)) return check("mcnerf_pack_weights_16", mcnx3_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, range_flags, (hipStream_t)stream));
     return check("mcnerf_pack_weights_16", mcn16_launch_pack(mcn_make_layout(depth, width, skip), params, packed_fwd, packed_bwd, dtype, range_flags, (hipStream_t)stream));
 }
 static size_t slot_bytes_of(int dtype, long long capacity, int width) { return dtype == 2 ? mcnx3_slot_bytes(capacity, width) : mcn16_slot_bytes(capacity, width); }
@@ -232,7 +235,7 @@ long long mcnerf_ws_bytes_16(int depth, int width, int dtype, long long capacity
         case 1: return (long long)(x3 ? mcnx3_enc_bytes(capacity) : mcn16_enc_bytes(capacity));
         case 2: return (long long)(depth + 2) * (long long)mcn16_mask_slot_bytes(capacity, width);
         case 3: return (long long)(x3 ? mcnx3_dsh_bytes(capacity) : mcn16_dsh_bytes(capacity));
-        case 4: return (long long)(x3 ? mcnx3_sh_bytes(capacity) : mcn16_dsh_bytes(capacity));
+        case 4: return (long long)(x3_chain(dtype) ? mcnx3_sh_bytes(capacity) : mcn16_dsh_bytes(capacity));      // (the chains' fp32 sh.2 tile)
     }
     return -1;
 }
@@ -251,12 +254,12 @@ int mcnerf_mlp_fwd_16(int depth, int width, int skip, int dtype, const float* pa
     Mcn16FwdArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
     a.params = params; a.packed = packed_fwd; a.bf16 = dtype;
-    a.stream_slabs = dtype == 2 ? mcnx3_fwd_stream(a.lay).total_frags / MCNX3_SLABF : mcn16_fwd_stream(a.lay).total_frags / MCN16_SLAB;
+    a.stream_slabs = x3_chain(dtype) ? mcnx3_fwd_stream(a.lay).total_frags / MCNX3_SLABF : mcn16_fwd_stream(a.lay).total_frags / MCN16_SLAB;
     a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter; a.barf_w = barf_w;
     a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S; a.out = out;
     a.act_ws = act_ws; a.slot_bytes = slot_bytes_of(dtype, capacity, width); a.enc_ws = enc_ws;
     a.mask_ws = mask_ws; a.mask_slot_words = mcn16_mask_slot_bytes(capacity, width) / 4; a.sh_ws = sh_ws;
-    return check("mcnerf_mlp_fwd_16", dtype == 2 ? mcnx3_launch_fwd(a, (hipStream_t)stream) : mcn16_launch_fwd(a, (hipStream_t)stream));
+    return check("mcnerf_mlp_fwd_16", x3_chain(dtype) ? mcnx3_launch_fwd(a, (hipStream_t)stream) : mcn16_launch_fwd(a, (hipStream_t)stream));
 }
 int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* params, const void* packed_bwd,
                       const float* rays_o, const float* rays_d, const float* zgrid, const float* jitter,
@@ -272,13 +275,13 @@ int mcnerf_mlp_bwd_16(int depth, int width, int skip, int dtype, const float* pa
     Mcn16BwdArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
     a.params = params; a.packed = packed_bwd; a.bf16 = dtype;
-    a.stream_slabs = dtype == 2 ? mcnx3_bwd_stream(a.lay).total_frags / MCNX3_SLABF : mcn16_bwd_stream(a.lay).total_frags / MCN16_SLAB;
+    a.stream_slabs = x3_chain(dtype) ? mcnx3_bwd_stream(a.lay).total_frags / MCNX3_SLABF : mcn16_bwd_stream(a.lay).total_frags / MCN16_SLAB;
     a.rays_o = rays_o; a.rays_d = rays_d; a.zgrid = zgrid; a.jitter = jitter; a.barf_w = barf_w;
     a.idx = (const int2*)idx; a.count = count; a.max_rows = max_rows; a.n_rays = n_rays; a.S = S;
     a.out = out; a.d_out = d_out; a.mask_ws = mask_ws; a.mask_slot_words = mcn16_mask_slot_bytes(capacity, width) / 4;
     a.enc_ws = enc_ws; a.sh_ws = sh_ws; a.dy_ws = dy_ws; a.slot_bytes = slot_bytes_of(dtype, capacity, width); a.dsh_ws = dsh_ws;
     a.d_rays_o = d_rays_o; a.d_rays_d = d_rays_d; a.gmax_bits = gmax_bits;
-    return check("mcnerf_mlp_bwd_16", dtype == 2 ? mcnx3_launch_bwd(a, (hipStream_t)stream) : mcn16_launch_bwd(a, (hipStream_t)stream));
+    return check("mcnerf_mlp_bwd_16", x3_chain(dtype) ? mcnx3_launch_bwd(a, (hipStream_t)stream) : mcn16_launch_bwd(a, (hipStream_t)stream));
 }
 int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const int32_t* count, int rows,
                      const void* act_ws, const void* enc_ws, const void* dy_ws, const void* dsh_ws,
@@ -287,8 +290,9 @@ int mcnerf_mlp_dw_16(int depth, int width, int skip, int dtype, const int32_t* c
     REQ(act_ws && enc_ws && dy_ws && dsh_ws && grads && gmax_bits && rows >= 0 && capacity >= rows, "mcnerf_mlp_dw_16");
     Mcn16DwArgs a;
     a.lay = mcn_make_layout(depth, width, skip);
-    a.bf16 = dtype; a.count = count; a.rows = rows; a.act_ws = act_ws; a.enc_ws = enc_ws; a.dy_ws = dy_ws; a.dsh_ws = dsh_ws;
+    a.bf16 = dtype == 3 ? 0 : dtype; a.count = count; a.rows = rows; a.act_ws = act_ws; a.enc_ws = enc_ws; a.dy_ws = dy_ws; a.dsh_ws = dsh_ws;
     a.slot_bytes = slot_bytes_of(dtype, capacity, width); a.grads = grads; a.gmax_bits = gmax_bits;
+    a.x_scale = dtype == 3 ? MCNX3_SX : 1.f;           // (dtype 3: f16 hi planes of the split-f16 chains, activations x 2^3)
     return check("mcnerf_mlp_dw_16", dtype == 2 ? mcnx3_launch_dw(a, (hipStream_t)stream) : mcn16_launch_dw(a, (hipStream_t)stream));
 }
 

@@ -105,7 +105,7 @@ struct Mcn16FwdArgs {
     const float* params;        // flat fp32 parameters (biases, sigma.2)
     const void* packed;         // forward stream (mcn16_fwd_stream order), 16-bit
     int stream_slabs;           // total_frags / 16
-    int bf16;                   // 0 = f16, 1 = bf16
+    int bf16;                   // 0 = f16, 1 = bf16; the split-f16 launchers: 2 = (hi, lo) workspaces, 3 = hi planes only (16-bit layout)
     const float* rays_o; const float* rays_d; const float* zgrid; const float* jitter; const float* barf_w;
     const int2* idx; const int* count; int max_rows; int n_rays, S;
     float* out;                 // [n_rays,S,4]
@@ -144,6 +144,7 @@ struct Mcn16DwArgs {
     size_t slot_bytes;
     float* grads;
     const unsigned* gmax_bits;
+    float x_scale;              // scale of the X planes (0 / 1: none; MCNX3_SX for the hi planes of the split-f16 chains, dtype 3)
 };
 hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st);
 hipError_t mcn16_launch_pack(const McnLayout& L, const float* params, void* packed_fwd, void* packed_bwd, int bf16, unsigned* range_flags, hipStream_t st);

@@ -52,7 +52,7 @@ constexpr int dw16_pick(int N, int K, bool want_vn) {
 // tiles [t0, t1) of one segment: stream, accumulate, flush.  Leaves no LDS-DMA piece outstanding and every wave past the
 // barrier that follows the last LDS read, so the next segment's run may refill the ring at once.
 template <int N, int K1, int K2, bool BF>
-__device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const int t1, const float sgs, char* smem) {
+__device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const int t1, const float sgs, const float xs, char* smem) {
     using T = Mcn16T<BF>;
     constexpr int K = K1 + K2;                                        // the X2 columns follow the X columns
     constexpr int KSN = N / 16, KSK1 = K1 / 16, KSK2 = K2 / 16, P = KSN + KSK1 + KSK2;   // 1 KiB pieces per tile
@@ -186,7 +186,7 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
 #undef DW16_WAIT_ASM
     // ---- accumulators -> global (float atomics; one register = two 128-byte row segments)
     const int r = lane & 31, h = lane >> 5;
-    const float inv = 1.0f / sgs;
+    const float inv = 1.0f / (sgs * xs), inv_b = 1.0f / sgs;      // (xs: the scale the X planes carry -- 1, or the split-f16 chains' 2^3 in the hi-plane mode)
     if (!(sg.kmap | sg.kmap2 | sg.nmap)) {
 #pragma unroll
         for (int t = 0; t < VN; ++t)
@@ -212,7 +212,7 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
         if (bias) {
 #pragma unroll
             for (int t = 0; t < VN; ++t) {
-                const float b = (bsum[t] + __shfl_xor(bsum[t], 32)) * inv;
+                const float b = (bsum[t] + __shfl_xor(bsum[t], 32)) * inv_b;
                 const int n = nbase + 32 * t + r;
                 if (h == 0 && n >= sg.n_lo && n < sg.n_real) atomicAdd(sg.db + (n - sg.n_lo), b);
             }
@@ -245,7 +245,7 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
         if (bias) {
 #pragma unroll
             for (int t = 0; t < VN; ++t) {
-                const float b = (bsum[t] + __shfl_xor(bsum[t], 32)) * inv;
+                const float b = (bsum[t] + __shfl_xor(bsum[t], 32)) * inv_b;
                 const int n = nbase + 32 * t + r;
                 const int nr = sg.nmap ? mcn_sh_row(n - sg.n_lo, sg.nmap - 16) : n - sg.n_lo;
                 if (h == 0 && n >= sg.n_lo && n < sg.n_real && nr >= 0) atomicAdd(sg.db + nr, b);
@@ -258,6 +258,7 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
 #define DW16_MAXSEG 15
 struct Dw16Job {
     int n;
+    float x_scale;                // power-of-two scale of the X planes (1; MCNX3_SX when the planes are the split-f16 chains' hi planes)
     int shape[DW16_MAXSEG];       // 0: W x W   1: W x 64 (encoded-input columns)   2: 32 x W (sh.2 / sigma.2 rows)   3: W x (W + 64) (skip layer)
     Dw16Seg seg[DW16_MAXSEG];
 };
@@ -288,10 +289,10 @@ __global__ __launch_bounds__(64 * MCN16_WAVES) void dw16_stream_kernel(Dw16Job j
         const int t0 = (int)(a < 0 ? 0 : a > ntiles ? ntiles : a), t1 = (int)(e < 0 ? 0 : e > ntiles ? ntiles : e);
         base += (long long)P * ntiles;
         if (t0 >= t1) continue;                                        // (block-uniform)
-        if (shape == 0) dw16_run<W, W, 0, BF>(job.seg[s], t0, t1, sgs, smem);
-        else if (shape == 1) dw16_run<W, 16 * MCN16_ENCKS, 0, BF>(job.seg[s], t0, t1, sgs, smem);
-        else if (shape == 2) dw16_run<32, W, 0, BF>(job.seg[s], t0, t1, sgs, smem);
-        else if constexpr (SKIP_MERGED) dw16_run<W, W, 16 * MCN16_ENCKS, BF>(job.seg[s], t0, t1, sgs, smem);
+        if (shape == 0) dw16_run<W, W, 0, BF>(job.seg[s], t0, t1, sgs, job.x_scale, smem);
+        else if (shape == 1) dw16_run<W, 16 * MCN16_ENCKS, 0, BF>(job.seg[s], t0, t1, sgs, job.x_scale, smem);
+        else if (shape == 2) dw16_run<32, W, 0, BF>(job.seg[s], t0, t1, sgs, job.x_scale, smem);
+        else if constexpr (SKIP_MERGED) dw16_run<W, W, 16 * MCN16_ENCKS, BF>(job.seg[s], t0, t1, sgs, job.x_scale, smem);
     }
 }
 
@@ -335,6 +336,7 @@ hipError_t mcn16_launch_dw(const Mcn16DwArgs& a, hipStream_t st) {
     const char* dsh = reinterpret_cast<const char*>(a.dsh_ws);
     Dw16Job job;
     job.n = 0;
+    job.x_scale = a.x_scale > 0.f ? a.x_scale : 1.f;
     auto add = [&](int shape, const Dw16Seg& s) { job.shape[job.n] = shape; job.seg[job.n] = s; ++job.n; };
     if (D + 5 > DW16_MAXSEG) return hipErrorInvalidValue;
     const bool merged = (W == 256 || W == 128);       // (Dw16SkipMerged)

@@ -30,7 +30,8 @@ struct BwdX3Smem {
 //   MODE 1: out = mask(split(acc / SW)), saved                   (masked by the forward's ReLU bits `mk`)
 //   MODE 2: as 1, with the accumulator started at the partial sum already in out
 //   MODE 3: NTILES == 2: acc2[t] += ...                          (fp32 accumulators owned by the caller, no epilogue)
-template <int W, int KSTEPS, int NTILES, int MODE, int PPW>
+//   HI: only the hi plane of a saved dY is written, in the 16-bit modes' workspace layout (dtype 3)
+template <int W, int KSTEPS, int NTILES, int MODE, int PPW, bool HI>
 __device__ __forceinline__ void mcnx3_bwd_seg(Mcn16Ring& ring, char* smem, int lane,
                                               const u32x4_t (&inh)[W / 16], const u32x4_t (&inl)[W / 16],
                                               u32x4_t (&outh)[W / 16], u32x4_t (&outl)[W / 16],
@@ -86,7 +87,7 @@ __device__ __forceinline__ void mcnx3_bwd_seg(Mcn16Ring& ring, char* smem, int l
         } else {
             const int k = i - 16, s = 2 * t + (k & 1);
             if (k < 2) mcn16_ws_store(outh[s], reinterpret_cast<u32x4_t*>(save_lane + s * 1024));
-            else mcn16_ws_store(outl[s], reinterpret_cast<u32x4_t*>(save_lane + (KS + s) * 1024));
+            else if (!HI) mcn16_ws_store(outl[s], reinterpret_cast<u32x4_t*>(save_lane + (KS + s) * 1024));      // (HI: the item keeps its gap, without the store)
         }
     };
     cur.cur = ring.next_off;
@@ -142,9 +143,10 @@ __device__ __forceinline__ void mcnx3_bwd_seg(Mcn16Ring& ring, char* smem, int l
     }
 }
 
-template <int W>
+template <int W, bool HI>
 __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x3_bwd_kernel(Mcn16BwdArgs a) {
     using SM = BwdX3Smem<W>;
+    constexpr int PL = HI ? 1 : 2;                 // fragment planes per saved tile
     constexpr int WAVES = mcnx3_waves(W), ROWS = 32 * WAVES, PPW = 16 / WAVES;
     constexpr int NT = W / 32, KS = W / 16, MW = W >= 64 ? W / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         const long long g = tile * 32 + m;
         const bool valid = g < total;
         const unsigned* mask_lane = a.mask_ws + ((size_t)tile * 64 + lane) * MW;
-        char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)tile * (2 * KS) * 1024 + lane * 16;
+        char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)tile * (PL * KS) * 1024 + lane * 16;
         // ---- per-sample prologue (lane-local): sigmoid and SH backward
         if (PREFB) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_TOP) : "memory");       // (the first pass: vmcnt(0) was waited for below the mask prefetch)
@@ -312,11 +314,13 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
                 dshh[s][d] = wh; dshl[s][d] = wl;
             }
         {
-            char* e = reinterpret_cast<char*>(a.dsh_ws) + (size_t)tile * 4 * 1024 + lane * 16;
+            char* e = reinterpret_cast<char*>(a.dsh_ws) + (size_t)tile * (PL * 2) * 1024 + lane * 16;
             mcn16_ws_store(dshh[0], reinterpret_cast<u32x4_t*>(e));
             mcn16_ws_store(dshh[1], reinterpret_cast<u32x4_t*>(e + 1024));
-            mcn16_ws_store(dshl[0], reinterpret_cast<u32x4_t*>(e + 2048));
-            mcn16_ws_store(dshl[1], reinterpret_cast<u32x4_t*>(e + 3072));
+            if (!HI) {
+                mcn16_ws_store(dshl[0], reinterpret_cast<u32x4_t*>(e + 2048));
+                mcn16_ws_store(dshl[1], reinterpret_cast<u32x4_t*>(e + 3072));
+            }
         }
 
         // (the first three mask slots and the per-sample inputs were fetched during the previous pass and waited for at its end)
@@ -363,22 +367,22 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
                 xal[s][d] = mcn16_pkmul(wl, bits);
             }
             mcn16_ws_store(xah[s], reinterpret_cast<u32x4_t*>(dy_lane + (size_t)D * a.slot_bytes + s * 1024));
-            mcn16_ws_store(xal[s], reinterpret_cast<u32x4_t*>(dy_lane + (size_t)D * a.slot_bytes + (KS + s) * 1024));
+            if (!HI) mcn16_ws_store(xal[s], reinterpret_cast<u32x4_t*>(dy_lane + (size_t)D * a.slot_bytes + (KS + s) * 1024));
         }
         // ---- sigma.0^T (partial, (hi, lo)) ; sh.2^T -> dY of sh.0 ; sh.0^T + partial -> dY_{D-1}
         if (D >= 2) mask_issue(mask_lane, D - 2, buf_of(D - 2));          // buffer 0 is free (the sigma path is done)
         unsigned mpend[MW];
         if (!MASK_DMA && D >= 2) mask_read(mask_lane, mpend, 0, D - 2);
-        mcnx3_bwd_seg<W, KS, NT, 0, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_s, denc, nullptr);
+        mcnx3_bwd_seg<W, KS, NT, 0, PPW, HI>(ring, smem, lane, xah, xal, xbh, xbl, mk_s, denc, nullptr);
         if (MASK_DMA) mask_read(mask_lane, mk_c, 1, D + 1);
         {
             u32x4_t dih[KS], dil[KS];
             dih[0] = dshh[0]; dih[1] = dshh[1]; dil[0] = dshl[0]; dil[1] = dshl[1];
-            mcnx3_bwd_seg<W, 2, NT, 1, PPW>(ring, smem, lane, dih, dil, xah, xal, mk_c, denc, dy_lane + (size_t)(D + 1) * a.slot_bytes);
+            mcnx3_bwd_seg<W, 2, NT, 1, PPW, HI>(ring, smem, lane, dih, dil, xah, xal, mk_c, denc, dy_lane + (size_t)(D + 1) * a.slot_bytes);
         }
         if (D >= 3) mask_issue(mask_lane, D - 3, buf_of(D - 3));          // buffer 1 is free (sh.2^T is done)
         if (MASK_DMA) mask_read(mask_lane, mk_t, 2, D - 1);
-        mcnx3_bwd_seg<W, KS, NT, 2, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, dy_lane + (size_t)(D - 1) * a.slot_bytes);
+        mcnx3_bwd_seg<W, KS, NT, 2, PPW, HI>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, dy_lane + (size_t)(D - 1) * a.slot_bytes);
         // ---- trunk, last layer to first, two layers per trip (dY_l in xb -> dY_{l-1} in xa -> dY_{l-2} in xb: no copies between layers)
         auto trunk_masks = [&](int l) {
             if (MASK_DMA) {
@@ -411,13 +415,13 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         for (int l = D - 1; l >= 1; l -= 2) {
             if (PREFB && l == 1) next_rows();
             trunk_masks(l);
-            if (l == skip) mcnx3_bwd_seg<W, KS, 2, 3, PPW>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, nullptr);      // encoded columns of the skip layer
-            mcnx3_bwd_seg<W, KS, NT, 1, PPW>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, dy_lane + (size_t)(l - 1) * a.slot_bytes);
+            if (l == skip) mcnx3_bwd_seg<W, KS, 2, 3, PPW, HI>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, nullptr);      // encoded columns of the skip layer
+            mcnx3_bwd_seg<W, KS, NT, 1, PPW, HI>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, dy_lane + (size_t)(l - 1) * a.slot_bytes);
             if (l - 1 >= 1) {
                 if (PREFB && l - 1 == 1) next_rows();
                 trunk_masks(l - 1);
-                if (l - 1 == skip) mcnx3_bwd_seg<W, KS, 2, 3, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, nullptr);
-                mcnx3_bwd_seg<W, KS, NT, 1, PPW>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, dy_lane + (size_t)(l - 2) * a.slot_bytes);
+                if (l - 1 == skip) mcnx3_bwd_seg<W, KS, 2, 3, PPW, HI>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, nullptr);
+                mcnx3_bwd_seg<W, KS, NT, 1, PPW, HI>(ring, smem, lane, xah, xal, xbh, xbl, mk_t, denc, dy_lane + (size_t)(l - 2) * a.slot_bytes);
             } else {               // an even trunk depth ends in xa: one copy per pass
 #pragma unroll
                 for (int s = 0; s < KS; ++s) { xbh[s] = xah[s]; xbl[s] = xal[s]; }
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
             for (int q = 0; q < 4; ++q)
                 shs[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 4096 + q * 1024 + lane * 16);
         }
-        mcnx3_bwd_seg<W, KS, 2, 3, PPW>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, nullptr);       // layer 0: encoded columns
+        mcnx3_bwd_seg<W, KS, 2, 3, PPW, HI>(ring, smem, lane, xbh, xbl, xah, xal, mk_t, denc, nullptr);       // layer 0: encoded columns
         auto settle = [&]() {
             if (PREFB && D >= 2) return;     // (wide net: nothing to wait for here -- the gathers are waited for at the top of the coming pass)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -553,7 +557,7 @@ static hipError_t launch_bwd_x3(const Mcn16BwdArgs& a, long long max_rows, hipSt
 #ifdef MCNERF_EXPERIMENTS      // (scripts/experiments/overlap_probe.py: a grid cap read per launch; not in the product build)
     if (const char* e = getenv("MCNERF_EXP_CHAIN_GRID")) { int g = atoi(e); if (g > 0 && g < grid) grid = g; }
 #endif
-    void (*kern)(Mcn16BwdArgs) = mlp_x3_bwd_kernel<W>;
+    void (*kern)(Mcn16BwdArgs) = a.bf16 == 3 ? mlp_x3_bwd_kernel<W, true> : mlp_x3_bwd_kernel<W, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), SM::total, st, a);

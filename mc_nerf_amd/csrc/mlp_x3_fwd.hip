@@ -25,17 +25,21 @@ struct FwdX3Smem {
 // Software pipeline pinned with sched_barriers: A pieces are read MCNX3_PF k-steps ahead; the epilogue of tile t (16 work
 // items of <= 9 vector instructions + 4 stores) is issued one item per MFMA gap of tile t + 1, whose accumulator is the
 // other of two register sets and starts at the (scaled) bias.
-template <int W, bool SAVE, int KENC, int KHID, int EPI, int PPW>
+//   SV 0: nothing saved; 1: the (hi, lo) fragment planes + ReLU bits; 2: the hi plane only, in the 16-bit modes' workspace layout (dtype 3:
+//   the weight-gradient kernel of that mode is the single-pass f16 one on the hi planes)
+template <int W, int SV, int KENC, int KHID, int EPI, int PPW>
 __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lane,
                                             const u32x4_t (&ench)[MCN16_ENCKS], const u32x4_t (&encl)[MCN16_ENCKS],
                                             const u32x4_t (&inh)[W / 16], const u32x4_t (&inl)[W / 16],
                                             u32x4_t (&outh)[W / 16], u32x4_t (&outl)[W / 16], const float* bias_h,
                                             const float* w2_h, float& dot, char* save_lane, unsigned* mask_lane) {
+    constexpr bool SAVE = SV != 0, HI = SV == 2;
     constexpr int NT = W / 32, KS = W / 16, KTOT = KENC + KHID, F = NT * KTOT, MW = W >= 64 ? W / 64 : 1;
     constexpr int G = 3 * KTOT;                                   // MFMA gaps per tile
     constexpr bool HAS2 = SAVE || EPI == 1;                       // a word has a second item (ReLU bit, sigma dot)
     constexpr int IPW = HAS2 ? 3 : 2;                             // items per packed word
-    constexpr int NIT = 8 * IPW + (SAVE ? 4 : 0);                 // work items of one tile's epilogue (each <= 6 vector instructions)
+    constexpr int NST = SAVE ? (HI ? 2 : 4) : 0;                  // fragment stores of a tile
+    constexpr int NIT = 8 * IPW + NST;                            // work items of one tile's epilogue (each <= 6 vector instructions)
     // Placement of a tile's epilogue in the gaps of the next tile.  With fragment stores (SAVE) and room for it: the word items from
     // gap 3 (the previous tile's last MFMA must have landed), IPG per gap, then the four stores one every SSTR gaps over the rest of
     // the tile instead of back to back (same-box A/B, 3.28 M rows of the 256-wide net: saving forward 12.12 -> 11.72 ms, backward
@@ -43,7 +47,7 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
     // items in order, as many per gap as it takes.
     constexpr int NWI = 8 * IPW;                                  // word items
 #ifndef MCNX3_NO_SPREAD
-    constexpr int ROOM = G - 3 - 8;                               // gaps for the word items when every store gets two
+    constexpr int ROOM = G - 3 - 2 * NST;                         // gaps for the word items when every store gets two
     constexpr int IPGA = ROOM > 0 ? (NWI + ROOM - 1) / ROOM : 99;
     constexpr bool STAG = SAVE && IPGA <= 2;
 #else
@@ -54,7 +58,7 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
     constexpr int IPG = STAG ? IPGA : (NIT + (G - START) - 1) / (G - START);    // items per gap
     constexpr int NITG = STAG ? NWI : NIT;                        // items placed by the items-per-gap rule
     constexpr int LASTG = START + (NITG + IPG - 1) / IPG - 1;     // gap of the last of them
-    constexpr int SBASE = LASTG + 1, SSTR = STAG ? (G - SBASE) / 4 : 1;
+    constexpr int SBASE = LASTG + 1, SSTR = STAG ? (G - SBASE) / NST : 1;
     constexpr int BIAS_G = (G - 6) > LASTG ? (G - 6) : LASTG;     // the next tile's accumulator (= the set just drained) is loaded here
     Mcn16Cursor cur;
     unsigned mw[MW];
@@ -101,7 +105,7 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
             const int k = i - 8 * IPW;           // 0, 1: hi plane k-steps 2t, 2t + 1; 2, 3: lo plane
             const int s = 2 * t + (k & 1);
             if (k < 2) mcn16_ws_store(outh[s], reinterpret_cast<u32x4_t*>(save_lane + s * 1024));
-            else mcn16_ws_store(outl[s], reinterpret_cast<u32x4_t*>(save_lane + (KS + s) * 1024));
+            else mcn16_ws_store(outl[s], reinterpret_cast<u32x4_t*>(save_lane + (KS + s) * 1024));      // (items k = 2, 3 do not exist with HI)
         }
     };
     cur.cur = ring.next_off;
@@ -136,7 +140,7 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
 #pragma unroll
                     for (int i = (gap - START) * IPG; i < (gap - START + 1) * IPG; ++i)
                         if (i < NITG) item(acc[(t - 1) & 1], t - 1, i);
-                    if (STAG && gap >= SBASE && (gap - SBASE) / SSTR < 4 && (gap - SBASE) % SSTR == 0)
+                    if (STAG && gap >= SBASE && (gap - SBASE) / SSTR < NST && (gap - SBASE) % SSTR == 0)
                         item(acc[(t - 1) & 1], t - 1, 8 * IPW + (gap - SBASE) / SSTR);
                 }
 #endif
@@ -171,9 +175,11 @@ extern "C" int mcnerf_debug_stamps_x3_fwd(unsigned long long* host_out) {
 #define MCNX3_FSTAMP(i) do { } while (0)
 #endif
 
-template <int W, bool SAVE>
+template <int W, int SV>
 __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x3_fwd_kernel(Mcn16FwdArgs a) {
     using SM = FwdX3Smem<W>;
+    constexpr bool SAVE = SV != 0, HI = SV == 2;
+    constexpr int PL = HI ? 1 : 2;                 // fragment planes per saved tile
     constexpr int WAVES = mcnx3_waves(W), ROWS = 32 * WAVES, PPW = 16 / WAVES;
     constexpr int KS = W / 16, MW = W >= 64 ? W / 64 : 1;
     constexpr float SXW = MCNX3_SX * MCNX3_SW;
@@ -301,14 +307,14 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
                     ench[s][d] = wh; encl[s][d] = wl;
                 }
         }
-        char* act_lane = SAVE ? reinterpret_cast<char*>(a.act_ws) + (size_t)tile * (2 * KS) * 1024 + lane * 16 : nullptr;
+        char* act_lane = SAVE ? reinterpret_cast<char*>(a.act_ws) + (size_t)tile * (PL * KS) * 1024 + lane * 16 : nullptr;
         unsigned* mask_lane = SAVE ? a.mask_ws + ((size_t)tile * 64 + lane) * MW : nullptr;
         if (SAVE) {
-            char* e = reinterpret_cast<char*>(a.enc_ws) + (size_t)tile * (2 * MCN16_ENCKS) * 1024 + lane * 16;
+            char* e = reinterpret_cast<char*>(a.enc_ws) + (size_t)tile * (PL * MCN16_ENCKS) * 1024 + lane * 16;
 #pragma unroll
             for (int s = 0; s < MCN16_ENCKS; ++s) {
                 mcn16_ws_store(ench[s], reinterpret_cast<u32x4_t*>(e + s * 1024));
-                mcn16_ws_store(encl[s], reinterpret_cast<u32x4_t*>(e + (MCN16_ENCKS + s) * 1024));
+                if (!HI) mcn16_ws_store(encl[s], reinterpret_cast<u32x4_t*>(e + (MCN16_ENCKS + s) * 1024));
             }
         }
 
@@ -317,19 +323,19 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         // ---- layer 0 (encoded input only), then the trunk two layers per trip (xb -> xa -> xb: no copies between layers);
         //      the skip layer takes [encoding, hidden]
         MCNX3_FSTAMP(1);
-        mcnx3_layer<W, SAVE, MCN16_ENCKS, 0, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h, nullptr, dot, act_lane, mask_lane);
+        mcnx3_layer<W, SV, MCN16_ENCKS, 0, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h, nullptr, dot, act_lane, mask_lane);
         MCNX3_FSTAMP(2);
         for (int l = 1; l < D; l += 2) {
             char* sl = SAVE ? act_lane + (size_t)l * a.slot_bytes : nullptr;
             unsigned* ml = SAVE ? mask_lane + (size_t)l * a.mask_slot_words : nullptr;
-            if (l == skip) mcnx3_layer<W, SAVE, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + l * W, nullptr, dot, sl, ml);
-            else mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + l * W, nullptr, dot, sl, ml);
+            if (l == skip) mcnx3_layer<W, SV, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + l * W, nullptr, dot, sl, ml);
+            else mcnx3_layer<W, SV, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + l * W, nullptr, dot, sl, ml);
             MCNX3_FSTAMP(2 + l);
             if (l + 1 < D) {
                 sl = SAVE ? act_lane + (size_t)(l + 1) * a.slot_bytes : nullptr;
                 ml = SAVE ? mask_lane + (size_t)(l + 1) * a.mask_slot_words : nullptr;
-                if (l + 1 == skip) mcnx3_layer<W, SAVE, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + (l + 1) * W, nullptr, dot, sl, ml);
-                else mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + (l + 1) * W, nullptr, dot, sl, ml);
+                if (l + 1 == skip) mcnx3_layer<W, SV, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + (l + 1) * W, nullptr, dot, sl, ml);
+                else mcnx3_layer<W, SV, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + (l + 1) * W, nullptr, dot, sl, ml);
                 MCNX3_FSTAMP(3 + l);
             } else {               // an even trunk depth ends in xa: one copy per pass
 #pragma unroll
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
             }
         }
         // ---- sigma head: hidden layer on the matrix pipe, the 1-wide output layer lane-local (on the fp32 activations)
-        mcnx3_layer<W, SAVE, 0, KS, 1, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + D * W, w2_h, dot,
+        mcnx3_layer<W, SV, 0, KS, 1, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + D * W, w2_h, dot,
                                             SAVE ? act_lane + (size_t)D * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)D * a.mask_slot_words : nullptr);
         MCNX3_FSTAMP(10);
         if (PREF) {                // the coming pass's rows: index pair from LDS, gathers by LDS-DMA (landed long before the pass ends)
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
             gather_dma(ray_n, j_n);
         }
         // ---- SH head: hidden layer (reads the same trunk output), then the 27 (32) coefficient rows
-        mcnx3_layer<W, SAVE, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + (D + 1) * W, nullptr, dot,
+        mcnx3_layer<W, SV, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + (D + 1) * W, nullptr, dot,
                                             SAVE ? act_lane + (size_t)(D + 1) * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)(D + 1) * a.mask_slot_words : nullptr);
         MCNX3_FSTAMP(11);
         f32x16 acc;
@@ -426,7 +432,7 @@ static hipError_t launch_fwd_x3(const Mcn16FwdArgs& a, long long max_rows, hipSt
     if (passes <= 0) return hipSuccess;
     const int grid = (int)(passes < cus ? passes : cus);
     const bool save = a.act_ws != nullptr;
-    void (*kern)(Mcn16FwdArgs) = save ? mlp_x3_fwd_kernel<W, true> : mlp_x3_fwd_kernel<W, false>;
+    void (*kern)(Mcn16FwdArgs) = save ? (a.bf16 == 3 ? mlp_x3_fwd_kernel<W, 2> : mlp_x3_fwd_kernel<W, 1>) : mlp_x3_fwd_kernel<W, 0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), SM::total, st, a);

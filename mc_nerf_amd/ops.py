@@ -157,10 +157,12 @@ def flatten_params(net: Net, tensors, device) -> Tensor:
 
 
 # --------------------------------------------------------------------------- ops
-PRECISIONS = ("f32", "f16x3", "f16", "bf16")
+PRECISIONS = ("f32", "f16x3", "f16x3h", "f16", "bf16")
 # register-chain modes: single-pass 16-bit MFMA (csrc/mcnerf_16.h) and split-f16 "f16x3" (csrc/mcnerf_x3.h): name -> dtype
 # code of the C ABI
-DTYPE16 = {"f16": 0, "bf16": 1, "f16x3": 2}
+# "f16x3h": the split-f16 forward / backward chains (colours and dX as in "f16x3") saving only the hi plane of every operand; the
+# weight gradient is the single-pass f16 kernel on those planes (dW operands rounded to 11 bits; 2-byte saved operands)
+DTYPE16 = {"f16": 0, "bf16": 1, "f16x3": 2, "f16x3h": 3}
 
 
 def is16(precision: str) -> bool:
@@ -198,7 +200,8 @@ def pack_weights(net: Net, params: Tensor, packed=None, precision: str = "f32", 
 # ---- range watch of the reduced-precision modes: (flags tensor, owner label, tensor names, precision) per net that has packed weights
 # with `range_flags`; read (one synchronisation) only when somebody asks why optimiser steps were refused
 _RANGE_WATCH = []
-RANGE_TEXT = {"f16": "|w| <= 65504", "bf16": "finite weights", "f16x3": "|w| <= 255.9 (the weights are scaled by 2^8 into f16)"}
+RANGE_TEXT = {"f16": "|w| <= 65504", "bf16": "finite weights", "f16x3": "|w| <= 255.9 (the weights are scaled by 2^8 into f16)",
+              "f16x3h": "|w| <= 255.9 (the weights are scaled by 2^8 into f16)"}
 
 
 def range_watch_register(flags: Tensor, label: str, names, precision: str):
@@ -547,7 +550,7 @@ def decode_frags_16(buf: Tensor, n_slots: int, width: int, rows: int, precision:
         x2 = buf.view(torch.float16).view(n_slots, -1, 2, ks, 2, 32, 8).float()
         x = x2[:, :, 0] + x2[:, :, 1]
     else:
-        dt = torch.float16 if precision == "f16" else torch.bfloat16
+        dt = torch.bfloat16 if precision == "bf16" else torch.float16        # ("f16x3h": the hi planes, an f16 workspace)
         x = buf.view(dt).view(n_slots, -1, ks, 2, 32, 8)        # [slot][tile][k-step][h][m][j]
     tiles = x.shape[1]
     s_, h_, j_ = torch.meshgrid(torch.arange(ks), torch.arange(2), torch.arange(8), indexing="ij")

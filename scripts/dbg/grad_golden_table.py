@@ -7,6 +7,22 @@ import numpy as np, torch
 from conftest import load_golden, t
 from test_model_gpu import build_model
 from mc_nerf_amd.model import MC_NeRF_Loss
+# DY_HI_ONLY=1 / X_HI_ONLY=1: what the f16x3 weight gradients would be with the lo plane of dY / of X left out of the weight-gradient
+# kernel (2 MFMAs per product, 3/4 of its bytes): the plane is zeroed between the backward chain and the weight-gradient call
+if os.environ.get("DY_HI_ONLY") or os.environ.get("X_HI_ONLY"):
+    from mc_nerf_amd import ops as _ops
+    _dw = _ops.mlp_dw
+    def _dw_dropped(net, save, dy, dsh, grads, rows, count=None, precision="f32", gmax=None):
+        if precision == "f16x3":
+            ks = net.width // 16
+            if os.environ.get("DY_HI_ONLY"):
+                dy.view(torch.float16).view(net.depth + 2, -1, 2, ks, 64, 8)[:, :, 1].zero_()
+                dsh.view(torch.float16).view(-1, 2, 2, 64, 8)[:, 1].zero_()
+            if os.environ.get("X_HI_ONLY"):
+                save.act.view(torch.float16).view(net.depth + 2, -1, 2, ks, 64, 8)[:, :, 1].zero_()
+                save.enc.view(torch.float16).view(-1, 2, 4, 64, 8)[:, 1].zero_()
+        return _dw(net, save, dy, dsh, grads, rows, count=count, precision=precision, gmax=gmax)
+    _ops.mlp_dw = _dw_dropped
 g = load_golden("g7_train_s64x2_full2048")
 dev = torch.device("cuda:0")
 res = {}

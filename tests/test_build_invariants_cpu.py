@@ -65,6 +65,8 @@ KNOWN_SCRATCH = {
     # 29 VGPRs: segment descriptors / source pointers of the one-launch job, stored in the kernel prologue and reloaded at each
     # segment's set-up and flush -- test_scratch_stays_out_of_the_mfma_loops shows none of it inside a tile loop
     "mlp_x3_dw.o": {"_Z18dwx3_stream_kernelILi256EEv7DwX3JobPKiiPKj": 128},
+    # the hi-plane saving forward (f16x3h): 5 VGPRs (two lane pointers and a dword), 12 scratch operations per pass of 2 640 MFMAs
+    "mlp_x3_fwd.o": {"_Z17mlp_x3_fwd_kernelILi256ELi2EEv12Mcn16FwdArgs": 32},
     "mlp16_bwd.o": {"_Z16mlp16_bwd_kernelILi256ELb1EEv12Mcn16BwdArgs": 160, "_Z16mlp16_bwd_kernelILi256ELb0EEv12Mcn16BwdArgs": 160},
     "mlp16_fwd.o": {"_Z16mlp16_fwd_kernelILi128ELb1ELb1EEv12Mcn16FwdArgs": 96},
     "mlp_fwd.o": {"_Z14mlp_fwd_kernelILi256ELb1EEv13McnMlpFwdArgs": 256, "_Z14mlp_fwd_kernelILi256ELb0EEv13McnMlpFwdArgs": 96},

@@ -47,7 +47,7 @@ def test_bench_line_contract():
             assert r["traffic_over_algorithmic"] == pytest.approx(r["step_traffic_bytes"] / r["algorithmic_bytes_per_step"])
         # the regime the target is stated for: pinned selected fractions, K reported with each
         for rho in ("0.25", "0.05"):
-            for p in ("f16x3", "f16"):
+            for p in (d["dtype"].split()[0], "f16"):       # the headline mode (f16x3 until r04n, f16x3h since) and f16
                 o = d["by_occupancy"][rho][p]
                 assert o["valid"] and abs(o["selected_fraction"] - float(rho)) < 0.3 * float(rho) and o["fine_samples_per_ray"] > 0
         for k in ("coarse_8x256x4", "rays_7000", "reference_default_128x5_rays_7000", "render"):
@@ -65,7 +65,7 @@ def test_bench_line_contract():
         assert d["by_precision"][p]["valid"] and d["by_precision"][p]["steps"] >= 20
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+@pytest.mark.parametrize("precision", ["f16x3h", "f16x3", "f16"])
 def test_pmc_traffic_belongs_to_the_sources_in_the_tree(precision):
     import bench
     rec = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{precision}.json")))

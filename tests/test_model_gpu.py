@@ -35,7 +35,7 @@ def err(a, b):
 TRAIN = ["g7_train_s64x2_small", "g7_train_s32x5_small_barf", "g7_train_s32x5_cap", "g7_train_s64x2_full"]
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h"])
 @pytest.mark.parametrize("name", TRAIN)
 def test_render_rays_train_matches_reference(gpu_device, name, precision):
     g = load_golden(name)
@@ -153,7 +153,7 @@ def test_multi_skip_topology_matches_reference(gpu_device):
         rgb, depth, opacity = m.render_rays_test(t(g["rays_d"]).to(dev), t(g["rays_o"]).to(dev), m.nerf_coarse, m.nerf_fine,
                                                  eps_c=t(g["eps_c"]).to(dev), eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
     assert float((rgb.cpu() - r["rgb"]).abs().max()) < TOL and float((depth.cpu() - r["depth"]).abs().max()) < TOL
-    for precision in ("f16x3", "f16", "bf16"):
+    for precision in ("f16x3", "f16x3h", "f16", "bf16"):
         with pytest.raises(ValueError, match="more than one skip layer"):
             NeRF_Model(make_sys_param(cfg, device=str(dev), mode=0, precision=precision))
 
@@ -166,10 +166,10 @@ def test_multi_skip_topology_matches_reference(gpu_device):
 # the whole-gradient gate (measured f16 2.1e-3, bf16 1.2e-2; per tensor they reach 0.18 on those near-cancelled sums) and their colours
 # to the oracle on the device's own selection (a weight within 16-bit rounding of the threshold flips a sample: bf16, degree 1);
 # what pins the index maps of these modes is test_chain_modes_scatter_smaller_nets_into_their_geometry.
-TOPO_TOL = {"f32": (TOL, 1e-4, 3e-4, 8.0, 1e-5), "f16x3": (TOL, 1e-4, 1.5e-2, 8.0, 1e-5), "f16": (1e-4, 1e-1, None, None, 1e-2), "bf16": (6e-4, 3e-1, None, None, 6e-2)}
+TOPO_TOL = {"f32": (TOL, 1e-4, 3e-4, 8.0, 1e-5), "f16x3": (TOL, 1e-4, 1.5e-2, 8.0, 1e-5), "f16x3h": (TOL, 1e-4, 1.5e-2, 8.0, 2e-4), "f16": (1e-4, 1e-1, None, None, 1e-2), "bf16": (6e-4, 3e-1, None, None, 6e-2)}
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h", "f16", "bf16"])
 @pytest.mark.parametrize("name", ["g7_train_s32x2_deg0", "g7_train_s32x2_deg1", "g7_train_s32x2_deg3", "g7_train_s32x2_freq6_barf"])
 def test_sh_degree_topology_matches_reference(gpu_device, name, precision):
     """General topology: `MLP_deg` 0, 1, 3 (model/net_block.py:43, 75-76; eval_sh up to degree 3, model/net_utils.py:103-179): 3, 12, 48
@@ -196,7 +196,7 @@ def test_sh_degree_topology_matches_reference(gpu_device, name, precision):
     o = t(g["rays_o"]).to(dev).requires_grad_(True)
     rgb_c, rgb_f = m.render_rays_train(d, o, 0, float(g["step_r"]), jitter=t(g["jitter"]).to(dev), eps_c=t(g["eps_c"]).to(dev),
                                        eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
-    if precision in ("f32", "f16x3"):
+    if precision in ("f32", "f16x3", "f16x3h"):
         assert err(rgb_c, g["rgb_c"]) < tol_rgb and err(rgb_f, g["rgb_f"]) < tol_rgb
     else:
         k = int(m.last_selection[1].item())
@@ -208,7 +208,7 @@ def test_sh_degree_topology_matches_reference(gpu_device, name, precision):
         assert abs(k - k_ref) <= max(2, k_ref // 200)
         assert err(rgb_c, r["rgb_c"]) < tol_rgb and err(rgb_f, r["rgb_f"]) < tol_rgb
     loss = MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([rgb_c, rgb_f, t(g["gt"]).to(dev)])
-    assert abs(float(loss.detach()) - float(g["loss"])) < (1e-5 if precision in ("f32", "f16x3") else 1e-3)
+    assert abs(float(loss.detach()) - float(g["loss"])) < (1e-5 if precision in ("f32", "f16x3", "f16x3h") else 1e-3)
     loss.backward()
     e_d = err(d.grad, g["d_rays_d"]) / float(np.abs(g["d_rays_d"]).max())
     e_o = err(o.grad, g["d_rays_o"]) / float(np.abs(g["d_rays_o"]).max())
@@ -259,10 +259,10 @@ def test_sh_degree_topology_matches_reference(gpu_device, name, precision):
 
 # per mode: (rgb abs, worst per-tensor gradient error as a multiple of the reference's own worst reorder noise, median over the
 # tensors likewise against the noise's median) -- measured f32 0.8 / 1.2, f16x3 1.8 / 16, f16 / bf16 their operand rounding
-FULL_TOL = {"f32": (1e-4, 2.0, 3.0), "f16x3": (1e-4, 4.0, 40.0), "f16": (5e-5, 60.0, 1500.0), "bf16": (4e-4, 300.0, 8000.0)}
+FULL_TOL = {"f32": (1e-4, 2.0, 3.0), "f16x3": (1e-4, 4.0, 40.0), "f16x3h": (1e-4, 4.0, 40.0), "f16": (5e-5, 60.0, 1500.0), "bf16": (4e-4, 300.0, 8000.0)}
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h", "f16", "bf16"])
 def test_full_size_gradient_golden(gpu_device, precision):
     """The at-size gradient pin: cfg-2 nets (coarse 4x128 + fine 8x256), 2048 rays, forward + backward of the ACTUAL reference
     (tests/golden/make_golden.py: g7_full_size; 0.2 M fine samples) -- rgb, loss, the ray gradients and, of each of the 40
@@ -312,10 +312,10 @@ def test_full_size_gradient_golden(gpu_device, precision):
     assert e_rgb < tol_rgb and abs(float(loss) - float(g["loss"])) < 1e-5
     assert e_worst < k_worst * n_worst, worst_key
     assert e_median < k_median * n_median
-    assert worst_norm < 0.1 * k_worst * n_worst + (0.0 if precision in ("f32", "f16x3") else 0.05)
+    assert worst_norm < 0.1 * k_worst * n_worst + (0.0 if precision in ("f32", "f16x3", "f16x3h") else 0.05)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h"])
 def test_render_coarse_only(gpu_device, precision):
     """BASELINE cfg 1's path: render_rays_train(only_coarse=True) (model/mc_nerf.py:598, 611-612) forward AND backward against
     the reference's golden: rgb / depth, every coarse-net gradient and the ray gradients."""
@@ -344,7 +344,7 @@ def test_render_coarse_only(gpu_device, precision):
     assert all(p.grad is None for p in m.nerf_fine.parameters())          # the fine net is not touched (:611)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h"])
 @pytest.mark.parametrize("name", ["g8_test_s64x2_small", "g8_test_s64x2_full", "g8_test_s128x5_small"])
 def test_render_rays_test_matches_reference(gpu_device, name, precision):
     g = load_golden(name)
@@ -477,7 +477,7 @@ def test_mc_model_demo_call(gpu_device):
     assert rgb.device.type == "cpu" and bool(torch.isfinite(rgb).all()) and float(opacity.min()) >= 0.0
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("f16", 2e-3)])
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("f16x3h", 1e-4), ("f16", 2e-3)])
 def test_demo_mode_from_reference_format_checkpoint_matches_oracle(gpu_device, tmp_path, precision, tol):
     """a reference-format checkpoint ({'model_nerf': MC_Model.state_dict()}, model/mc_nerf.py:738-752) is
     written by save_model, a fresh MC_Model is built in demo mode from `demo_ckpt` (:577-584, 815-837) and renders a whole
@@ -523,7 +523,7 @@ def test_demo_mode_from_reference_format_checkpoint_matches_oracle(gpu_device, t
     assert float(opacity.max()) > 0.5                       # the scene is not empty: the comparison means something
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h"])
 def test_valid_train_renders_the_checkpoint_just_saved(gpu_device, tmp_path, precision):
     """main.py:92-95's epoch end on the HIP path: save_model, then valid_train(epoch, rays_valid, "GLOBAL_OPTIM_EPOCH")
     (model/mc_nerf.py:754-813) re-loads the checkpoint JUST WRITTEN into fresh nets and renders the validation view in `batch`
@@ -734,7 +734,7 @@ def test_full_size_batch_subset_against_oracle(gpu_device, precision):
     assert ec < TOL and ef < TOL
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h"])
 @pytest.mark.parametrize("name,stage,opt_idx", [("g11_mc_model_step", "GLOBAL_OPTIM_EPOCH", 1), ("g11b_mc_model_cam_param", "CAM_PARAM_EPOCH", 0),
                                                 ("g11c_mc_model_fine_tune", "FINE_TUNE_EPOCH", 2)])
 def test_mc_model_step_matches_reference_golden(gpu_device, name, stage, opt_idx, precision):
@@ -931,7 +931,7 @@ def _full_size_inputs(n, cfg, dev, seed=11):
     return d, o, kw
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h", "f16", "bf16"])
 def test_full_size_permutation_and_repeatability(gpu_device, precision):
     """32768 rays at the bench configuration: rendering is a per-ray function (a permutation of the rays permutes the
     outputs bit-exactly, including through the device-side selection / compaction) and repeatable."""
@@ -989,7 +989,7 @@ def test_full_size_directional_derivative(gpu_device):
     assert abs(fd - analytic) <= 2e-2 * max(abs(analytic), 1e-4), (fd, analytic)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h"])
 @pytest.mark.parametrize("n", [1, 63, 257])
 def test_ragged_small_batches_match_oracle(gpu_device, n, precision):
     """Ray counts around the tile sizes (1 ray, 63, 257) on small nets, end to end against the CPU oracle."""
@@ -1041,7 +1041,7 @@ def test_background_and_barf_schedule_extremes(gpu_device, white_back, step_r):
             assert err(got, g.numpy()) < 1e-4 * max(1.0, float(g.abs().max())), k
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h"])
 def test_inference_and_sigma2weights_api(gpu_device, precision):
     """The reference's per-pass API (NeRF_Model.inference :682-727, sigma2weights :729-736) against the oracle: coarse
     pass on the dense grid and fine pass on an index list, with the reference's z_vals = grid + per-ray jitter."""
@@ -1106,7 +1106,7 @@ def test_full_size_precision_modes_agree(gpu_device):
     dev = gpu_device
     n = 16384
     res = {}
-    for precision in ("f32", "f16x3"):
+    for precision in ("f32", "f16x3", "f16x3h"):
         m, cfg = _full_size_model(dev, precision)
         d, o, kw = _full_size_inputs(n, cfg, dev, seed=23)
         gt = torch.rand(n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
@@ -1160,7 +1160,7 @@ def test_full_size_16bit_modes_against_f32(gpu_device):
         assert rel[0] < tol_grad and rel[1] < tol_grad
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "f16x3h", "f16", "bf16"])
 def test_full_size_cap_path(gpu_device, precision):
     """BASELINE configs[4]-like sampling (64 coarse + 256 fine grid, scale 4) on the full-size nets: more than 128 fine
     samples per ray get selected at random init, so the training cap (model/mc_nerf.py:630-632) binds -- exactly
@@ -1218,7 +1218,7 @@ def test_randomised_configs_match_oracle(gpu_device):
     import random
     from parity_fuzz import one_case
     rng = random.Random(2024)
-    res = [one_case(rng, gpu_device, verbose=False, general=(i % 3 == 2), modes=("f32", "f16x3", "f16", "bf16")) for i in range(36)]
+    res = [one_case(rng, gpu_device, verbose=False, general=(i % 3 == 2), modes=("f32", "f16x3", "f16x3h", "f16", "bf16")) for i in range(40)]
     assert all(r is True for r in res)
 
 
@@ -1283,6 +1283,43 @@ def test_standalone_module_forwards_match_reference_modules(gpu_device):
     assert not emb(x.to(dev), 0.5).requires_grad                   # nothing requires a gradient: plain inference call
 
 
+@pytest.mark.parametrize("name", ["g7_train_s64x2_small", "g7_train_s32x5_cap", "g7_train_s64x2_full"])
+def test_f16x3h_runs_the_f16x3_chains(gpu_device, name):
+    """`f16x3h` = the forward and backward (dX) chains of `f16x3`, saving only the hi plane of every operand, + the single-pass f16
+    weight-gradient kernel on those planes (include/mcnerf.h, dtype 3).  So against `f16x3` on the same inputs: colours, the
+    selection and the ray gradients are BIT-identical (same instructions on the same data); only the weight gradients differ, by
+    the rounding of their operands to 11 bits -- gated here at 1e-3 of a tensor's largest gradient or 5e-7 of the net's largest
+    (measured: <= 6e-4 on every tensor that carries a gradient above that floor)."""
+    from mc_nerf_amd.model import MC_NeRF_Loss
+    g = load_golden(name)
+    dev = gpu_device
+    res = {}
+    for precision in ("f16x3", "f16x3h"):
+        m, cfg, pc, pf = build_model(g, dev, precision=precision)
+        d = t(g["rays_d"]).to(dev).requires_grad_(True)
+        o = t(g["rays_o"]).to(dev).requires_grad_(True)
+        kw = dict(jitter=t(g["jitter"]).to(dev), eps_c=t(g["eps_c"]).to(dev), eps_sel=t(g["eps_sel"]).to(dev), eps_f=t(g["eps_f"]).to(dev))
+        if "cap_perm" in g:
+            kw["cap_perm"] = t(g["cap_perm"])
+        rgb_c, rgb_f = m.render_rays_train(d, o, 0, float(g["step_r"]), **kw)
+        MC_NeRF_Loss(dict(data_img_h=800, data_img_w=800)).get_rgb_loss([rgb_c, rgb_f, t(g["gt"]).to(dev)]).backward()
+        k = int(m.last_selection[1].item())
+        res[precision] = (rgb_c.detach(), rgb_f.detach(), m.last_selection[0][:k].clone(), d.grad, o.grad,
+                          {f"{tag}.{k_}": p.grad for tag, net in (("c", m.nerf_coarse), ("f", m.nerf_fine)) for k_, p in net.named_parameters()})
+    a, b = res["f16x3"], res["f16x3h"]
+    for i in range(3):
+        assert torch.equal(a[i], b[i])
+    # (the ray gradients are sums of lane atomics: equal up to their order)
+    assert float((a[3] - b[3]).abs().max()) <= 1e-6 * float(a[3].abs().max()) and float((a[4] - b[4]).abs().max()) <= 1e-6 * float(a[4].abs().max())
+    gmax = max(float(v.abs().max()) for v in a[5].values())
+    worst = 0.0
+    for k_, ga in a[5].items():
+        e = float((ga - b[5][k_]).abs().max())
+        worst = max(worst, e / max(float(ga.abs().max()), 5e-4 * gmax))
+        assert e <= max(1e-3 * float(ga.abs().max()), 5e-7 * gmax), (k_, e, float(ga.abs().max()), gmax)
+    print(f"{name}: f16x3h vs f16x3 weight gradients: worst {worst:.1e} of a tensor's max (net-wide max {gmax:.1e})")
+
+
 def _enc_col(c, F):
     """csrc/mcnerf_common.h mcn_enc_col: column of the 10-frequency encoding -> column of an F-frequency one (None: no such channel)."""
     if c < 3:
@@ -1292,7 +1329,7 @@ def _enc_col(c, F):
     return 3 + a * 2 * F + sc * F + k if k < F else None
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16", "bf16"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3h", "f16", "bf16"])
 @pytest.mark.parametrize("name", ["g7_train_s32x2_deg0", "g7_train_s32x2_deg1", "g7_train_s32x2_freq6_barf"])
 def test_chain_modes_scatter_smaller_nets_into_their_geometry(gpu_device, name, precision):
     """The register-chain kernels have ONE geometry (SH degree 2, 10 encoding frequencies).  A net with a lower degree / fewer
