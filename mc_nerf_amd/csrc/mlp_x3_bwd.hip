@@ -10,6 +10,10 @@
 // mlp_x3_dw.hip), scaled by the per-launch power of two SG (f16 range; derived from max|d_out|).
 // Replaces autograd through model/net_block.py:22-33, 67-78 and model/mc_nerf.py:602, 635, 690-691.
 #include "mcnerf_x3.h"
+
+#ifndef MCNX3_BWD_PREF_MINW      // narrowest net whose per-sample inputs and ReLU bits arrive by LDS-DMA one pass ahead (a build knob for A/B timing)
+#define MCNX3_BWD_PREF_MINW 256
+#endif
 #include <cstdlib>
 
 template <int W>
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
     // compiler-visible load -- a pass then never drains the wave's vector-memory queue (the workspace stores of a pass take
     // microseconds to retire; a vmcnt(0) per pass waits for all of them, with the matrix pipe idle).  Landing is guaranteed by
     // counted waits: in-order completion, and at least N younger ring pieces issued since (N_* below).
-    constexpr bool PREFB = W >= 256;
+    constexpr bool PREFB = W >= MCNX3_BWD_PREF_MINW;
     constexpr int SLABS_FULL = (W / 32) * (W / 16) / MCNX3_SLABF;                       // ring slabs of one W x W segment
     constexpr int SLABS_ENC = (2 * (W / 16) + MCNX3_SLABF - 1) / MCNX3_SLABF;           // ... of a 2-tile encoded-column segment
     constexpr int N_IDX = PPW * (2 * SLABS_FULL - 1) < 63 ? PPW * (2 * SLABS_FULL - 1) : 63;      // index pairs: issued >= two W x W segments earlier
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
 
     // ReLU bits: LDS-DMA into one of this wave's three buffers well ahead of their use on the wide net, ordinary loads one
     // layer ahead on the narrow ones (mlp16_bwd.hip).  Slot x <= D-1 lives in buffer (D + 1 - x) % 3; D in 0, D + 1 in 1.
-    constexpr bool MASK_DMA = W >= 256;
+    constexpr bool MASK_DMA = W >= MCNX3_BWD_PREF_MINW;
     const unsigned mlds = ring.lds_base + SM::oMask + wave * (3 * MW * 256);
     auto mask_issue = [&](const unsigned* mask_lane, int slot, int buf) {
         if (MASK_DMA) {
