@@ -1,7 +1,7 @@
 """End-to-end convergence check on a PROCEDURAL scene (no dataset exists in the container): three soft coloured blobs
 on a white background, ground-truth images volume-rendered analytically with dense quadrature in plain torch, 110
 Ball-rig cameras with known poses.  Trains the coarse+fine nets through the HIP path (renderer fwd/bwd + fused RAdam) and
-reports PSNR of held-out views.  Usage (GPU box):  python scripts/train_procedural.py [f32|f16x3] [steps]
+reports PSNR of held-out views.  Usage (GPU box):  python scripts/train_procedural.py [f32|f16x3|f16x3h|f16|bf16] [steps]
 """
 import math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
