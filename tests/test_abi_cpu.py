@@ -96,3 +96,22 @@ def test_general_topology_codes_and_layouts(built_lib):
         ops.skip_code([2], 4, deg=4)
     with pytest.raises(ValueError):
         ops.skip_code([2], 4, n_freqs=11)
+
+
+def test_register_chain_dtypes_and_workspace_sizes(built_lib):
+    """`dtype` of the `_16` entry points (include/mcnerf.h): 0 = f16, 1 = bf16, 2 = f16x3 (hi + lo planes), 3 = f16x3h (f16x3's chains,
+    hi planes only): dtype 3 packs its weights like dtype 2, keeps dtype 2's fp32 sh.2-output tile, and sizes every other workspace
+    like dtype 0; anything else is refused."""
+    from mc_nerf_amd import ops
+    l = ops._lib.lib()
+    assert ops.DTYPE16 == {"f16": 0, "bf16": 1, "f16x3": 2, "f16x3h": 3} and set(ops.PRECISIONS) == {"f32", *ops.DTYPE16}
+    for depth, width, skip in ((8, 256, 4), (4, 128, 2), (8, 64, 4)):
+        for bwd in (0, 1):
+            assert l.mcnerf_packed_bytes_16(depth, width, skip, 3, bwd) == l.mcnerf_packed_bytes_16(depth, width, skip, 2, bwd) > l.mcnerf_packed_bytes_16(depth, width, skip, 0, bwd) > 0
+        for cap in (1, 4096, 3_200_000):
+            for which in (0, 1, 2, 3):
+                assert l.mcnerf_ws_bytes_16(depth, width, 3, cap, which) == l.mcnerf_ws_bytes_16(depth, width, 0, cap, which) > 0
+                if which != 2:
+                    assert l.mcnerf_ws_bytes_16(depth, width, 2, cap, which) == 2 * l.mcnerf_ws_bytes_16(depth, width, 0, cap, which)
+            assert l.mcnerf_ws_bytes_16(depth, width, 3, cap, 4) == l.mcnerf_ws_bytes_16(depth, width, 2, cap, 4) == 2 * l.mcnerf_ws_bytes_16(depth, width, 0, cap, 4)
+    assert l.mcnerf_packed_bytes_16(8, 256, 4, 4, 0) == -1 and l.mcnerf_ws_bytes_16(8, 256, -1, 4096, 0) == -1 and l.mcnerf_ws_bytes_16(8, 256, 4, 4096, 0) == -1
