@@ -107,7 +107,7 @@ def test_register_chain_dtypes_and_workspace_sizes(built_lib):
     assert ops.DTYPE16 == {"f16": 0, "bf16": 1, "f16x3": 2, "f16x3h": 3} and set(ops.PRECISIONS) == {"f32", *ops.DTYPE16}
     for depth, width, skip in ((8, 256, 4), (4, 128, 2), (8, 64, 4)):
         for bwd in (0, 1):
-            assert l.mcnerf_packed_bytes_16(depth, width, skip, 3, bwd) == l.mcnerf_packed_bytes_16(depth, width, skip, 2, bwd) > l.mcnerf_packed_bytes_16(depth, width, skip, 0, bwd) > 0
+            assert l.mcnerf_packed_bytes_16(depth, width, skip, 3, bwd) == l.mcnerf_packed_bytes_16(depth, width, skip, 2, bwd) >= l.mcnerf_packed_bytes_16(depth, width, skip, 0, bwd) > 0      # (slab padding differs between the streams)
         for cap in (1, 4096, 3_200_000):
             for which in (0, 1, 2, 3):
                 assert l.mcnerf_ws_bytes_16(depth, width, 3, cap, which) == l.mcnerf_ws_bytes_16(depth, width, 0, cap, which) > 0
