@@ -1,7 +1,7 @@
 """Randomised end-to-end parity sweep against the CPU oracle: random sample counts / scales / net shapes / ray counts /
 BARF / background / near-far / precision mode, non-unit directions; colours, the fine-sample selection (through the device's kept
 list when the 128-per-ray cap binds), every parameter gradient and the ray gradients are compared.  A fixed-seed subset runs in
-tests/test_model_gpu.py; as a script it sweeps more, all four modes and -- every third case -- a general topology (skip lists, SH degree, frequency count):
+tests/test_model_gpu.py; as a script it sweeps more, all five modes and -- every third case -- a general topology (skip lists, SH degree, frequency count):
     python tests/parity_fuzz.py [n_cases] [seed] [mode,mode,...]"""
 import os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1213,7 +1213,7 @@ def test_empty_and_single_ray_batches(gpu_device):
 
 
 def test_randomised_configs_match_oracle(gpu_device):
-    """A fixed-seed slice of tests/parity_fuzz.py: 36 random configurations end to end against the oracle -- all four precision
+    """A fixed-seed slice of tests/parity_fuzz.py: 40 random configurations end to end against the oracle -- all five precision
     modes at their gates, every third case a general topology (skip lists, SH degree, encoding frequencies) in the exact-fp32
     family, the 128-per-ray cap checked through the device's kept list whenever it binds."""
     import random
