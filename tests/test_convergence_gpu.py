@@ -82,6 +82,55 @@ def test_field_converges_in_the_split_f16_modes_and_tracks_f32(gpu_device):
     assert abs(ph - p32) < 3.0 and abs(lh - l32) < 0.4 * max(lh, l32)
 
 
+def _short_trajectory(dev, precision, steps, seed=3):
+    """`steps` optimiser steps of the full-size nets (coarse 4 x 128, fine 8 x 256) on the procedural scene from one seed (same
+    initial weights, pixel draws, jitter and noise in every mode: the device generator is re-seeded): the parameters afterwards."""
+    from mc_nerf_amd import ops, synthetic as S
+    from mc_nerf_amd.model import MC_NeRF_Loss, NeRF_Model, RAdam
+    torch.manual_seed(seed)
+    pose, K, _ = S.ball_cameras(seed=0, radius=3.0, H=H, W=W)
+    pose, K = pose.to(dev), K.to(dev)
+    Kinv = torch.linalg.inv(K)
+    imgs = S.blob_scene_images(pose, K, H, W)
+    sp = S.make_sys_param(dev, samples=64, scale=2, batch=2048, H=H, W=W, precision=precision)
+    torch.manual_seed(seed)
+    model = NeRF_Model(sp).to(dev)
+    opt = RAdam(model.parameters(), lr=5e-4, weight_decay=0.0)
+    loss_fn = MC_NeRF_Loss(sp)
+    init = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double()
+    torch.manual_seed(seed + 1)
+    for step in range(steps):
+        i = (7 * step) % pose.shape[0]
+        pix = torch.randperm(H * W, device=dev)[:2048]
+        d, o = ops.raygen_fwd(pose[i].contiguous(), Kinv[i].contiguous(), pix, W)
+        rgb_c, rgb_f = model.render_rays_train(d, o, step, 1.0)
+        loss = loss_fn.get_rgb_loss([rgb_c, rgb_f, imgs[i][pix]])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    assert int(opt.skipped_steps()) == 0
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double() - init      # what the steps did to the parameters
+
+
+def test_f16x3h_follows_the_f32_trajectory_as_closely_as_f16x3(gpu_device):
+    """What the hi-plane weight gradient of `f16x3h` does to TRAINING, not to one gradient: 30 optimiser steps of the full-size nets from
+    one seed in `f32`, `f16x3` and `f16x3h` (the same draws in every mode), then the distance of the accumulated UPDATES (final - initial
+    parameters) relative to the f32 run's update.  RAdam divides
+    every gradient by its running magnitude, so a gradient error shows up undamped in the weights; the exact-fp32 run done twice
+    gives the scatter of the comparison itself (the weight-gradient atomics add in another order every run).  `f16x3h` must stay
+    within 1.5 x `f16x3`'s distance from `f32` (+ that scatter), and the single-pass `f16` mode is printed beside them."""
+    dev = gpu_device
+    steps = 30
+    ref = _short_trajectory(dev, "f32", steps)
+    again = _short_trajectory(dev, "f32", steps)
+    dist = {p: float((_short_trajectory(dev, p, steps) - ref).norm() / ref.norm()) for p in ("f16x3", "f16x3h", "f16")}
+    scatter = float((again - ref).norm() / ref.norm())
+    print(f"{steps} steps, full-size nets, distance of the accumulated parameter update from the f32 run's, relative to that update: f32 again {scatter:.2e}, "
+          f"f16x3 {dist['f16x3']:.2e}, f16x3h {dist['f16x3h']:.2e}, f16 {dist['f16']:.2e}")
+    assert dist["f16x3h"] < 1.5 * dist["f16x3"] + 2.0 * scatter
+    assert dist["f16x3h"] < dist["f16"] or dist["f16"] < 2.0 * scatter
+
+
 def test_joint_stage_reduces_the_camera_rotation_error(gpu_device):
     from mc_nerf_amd import synthetic as S
     from mc_nerf_amd.data import DeviceImageSet
