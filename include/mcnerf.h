@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MCNERF_ABI_VERSION 5
+#define MCNERF_ABI_VERSION 6      /* 6: dtype 3 (f16x3h) of the register-chain entry points */
 
 int mcnerf_abi_version(void);
 const char* mcnerf_last_error(void);

@@ -15,7 +15,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MCNERF_LIB selects another build of the SAME library (kernel ablation / tuning variants, scripts/ablate.sh)
 LIB_PATH = os.environ.get("MCNERF_LIB") or os.path.join(_HERE, "libmcnerf.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _P = c_void_p
 _I = c_int
