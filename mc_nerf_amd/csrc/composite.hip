@@ -168,14 +168,21 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(McnCompositeBwdArgs 
             const float dw = g0 * (v[1] - wb) + g1 * (v[2] - wb) + g2 * (v[3] - wb);
             const float dsp = sx > 20.f ? 1.f : 1.f / (1.f + expf(-sx));      // d softplus
             sT[j] = T; sU[j] = u; sE[j] = ex * delta * dsp; sDW[j] = dw; sDWW[j] = dw * w;
-            f32x4 o; o[0] = 0.f; o[1] = w * g0; o[2] = w * g1; o[3] = w * g2;
-            dst[j] = o;
-            gmx = fmaxf(gmx, fmaxf(fabsf(o[1]), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+            // components 1..3 only: component 0 (d sigma) belongs to the lane that takes sample j in the suffix pass
+            float* o = reinterpret_cast<float*>(dst + j);
+            const float o1 = w * g0, o2 = w * g1, o3 = w * g2;
+            o[1] = o1;
+            *reinterpret_cast<f32x2*>(o + 2) = (f32x2){o2, o3};
+            gmx = fmaxf(gmx, fmaxf(fabsf(o1), fmaxf(fabsf(o2), fabsf(o3))));
         }
     }
+    // pass 1's LDS writes are read below by OTHER lanes of this wave: the hardware executes one wave's LDS operations in issue
+    // order, the fence + wave barrier keep the compiler from moving them across this line
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // suffix pass: lane l takes sample 63 - l of the chunk, so the sum of the samples AFTER a sample is an exclusive PREFIX scan over
-    // the lanes (the DPP scans run one way).  A lane reads what another lane of its own wave wrote: LDS operations of one wave
-    // execute in issue order, no barrier needed.
+    // the lanes (the DPP scans run one way).
     float carryR = 0.f;
     const int nch = (S + 63) / 64;
     for (int c = nch - 1; c >= 0; --c) {
@@ -191,6 +198,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(McnCompositeBwdArgs 
             gmx = fmaxf(gmx, fabsf(dsig));
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // the next ray's pass 1 rewrites the same LDS words
+    __builtin_amdgcn_wave_barrier();
     }
     if (a.gmax_bits) {
         gmx = wave_max(gmx);

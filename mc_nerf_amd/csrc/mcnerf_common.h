@@ -25,6 +25,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Offsets (in floats) of every tensor of one CorseFine_NeRF inside (a) the flat parameter buffer and
 // (b) the packed buffer.  Built on the host by mcn_make_layout(), passed to kernels by value.

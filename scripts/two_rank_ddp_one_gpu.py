@@ -10,10 +10,13 @@ import sys
 
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+from _ranks import PG_TIMEOUT, run_ranks        # noqa: E402
+
+BUDGET_S = 420      # < the pytest timeout of tests/test_z_multirank_gpu.py
 STAGES = ["CAM_PARAM_EPOCH"] * 2 + ["GLOBAL_OPTIM_EPOCH"] * 2 + ["FINE_TUNE_EPOCH"] * 2
 
 
@@ -36,13 +39,12 @@ def generate_optimizer(model, steps_per_epoch, RAdam):
     return [opt_cam, opt_global, opt_fine], [sched_cam, sched_global, sched_fine]
 
 
-def worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+def worker(rank, world, port):
     from mc_nerf_amd import distributed as D, synthetic as S
     from mc_nerf_amd.model import MC_Model, MC_NeRF_Loss, RAdam
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=PG_TIMEOUT)
     H = W = 48
     sp = S.make_sys_param(dev, samples=32, scale=2, batch=1024, H=H, W=W, coarse=(4, 32, [2]), fine=(8, 64, [4]), precision="f16x3")
     wpts, pts = S.calibration_points(sp["gt_pose"], sp["intr_mat"][0])
@@ -95,27 +97,15 @@ def worker(rank, world, port, q):
         del wrapped
     a, b = results["ddp"][0], results["flat"][0]
     rel = float((a - b).abs().max() / a.abs().max())
-    q.put((rank, results["ddp"][1], results["flat"][1], rel, results["ddp"][2] + results["flat"][2], results["asym"]))
+    res = (rank, results["ddp"][1], results["flat"][1], rel, results["ddp"][2] + results["flat"][2], results["asym"])
     dist.barrier()
     dist.destroy_process_group()
+    return res
 
 
 if __name__ == "__main__":
-    import socket
-    world = 2
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    ps = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
-    for p in ps:
-        p.start()
-    res = sorted(q.get(timeout=900) for _ in range(world))
-    for p in ps:
-        p.join(120)
+    res = run_ranks(worker, 2, BUDGET_S)
     print(res)
-    ok = all(r[1] and r[2] and r[3] < 1e-5 and r[4] == 0 and r[5] == 0 for r in res) and all(p.exitcode == 0 for p in ps)
+    ok = all(r[1] and r[2] and r[3] < 1e-5 and r[4] == 0 and r[5] == 0 for r in res)
     assert ok, "stock-DDP vs FlatGradSync check FAILED"
     print("stock DDP (find_unused_parameters) == FlatGradSync over 2 steps of each stage, replicas bit-identical: check: OK")

@@ -7,19 +7,21 @@ import sys
 
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+from _ranks import PG_TIMEOUT, run_ranks        # noqa: E402
+
+BUDGET_S = 300      # < the pytest timeout of tests/test_z_multirank_gpu.py
 
 
-def worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+def worker(rank, world, port):
     from mc_nerf_amd import distributed as D, synthetic as S
     from mc_nerf_amd.model import MC_Model, MC_NeRF_Loss, RAdam
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=PG_TIMEOUT)
     torch.manual_seed(42 + rank)
     H = W = 64
     sp = S.make_sys_param(dev, samples=64, scale=2, batch=2048, H=H, W=W)
@@ -55,26 +57,14 @@ def worker(rank, world, port, q):
     flat = torch.cat([n.flat_params() for n in sync.nets] + [p.detach().reshape(-1) for p in sync.cam_params])
     ref = flat.clone()
     dist.broadcast(ref, src=0)
-    q.put((rank, ok, bool(torch.equal(flat, ref)), float(loss.detach())))
+    res = (rank, ok, bool(torch.equal(flat, ref)), float(loss.detach()))
     dist.barrier()
     dist.destroy_process_group()
+    return res
 
 
 if __name__ == "__main__":
-    import socket
-    world = 2
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    ps = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
-    for p in ps:
-        p.start()
-    res = sorted(q.get(timeout=600) for _ in range(world))
-    for p in ps:
-        p.join(120)
+    res = run_ranks(worker, 2, BUDGET_S)
     print(res)
-    assert all(r[1] and r[2] for r in res) and all(p.exitcode == 0 for p in ps), "two-rank check FAILED"
+    assert all(r[1] and r[2] for r in res), "two-rank check FAILED"
     print("two-rank one-GPU data-parallel check: OK")

@@ -54,6 +54,17 @@ def nets_from_golden(g, cfg):
     return pc, pf
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _give_back_gpu_cache_between_modules():
+    """A test module's big workspaces (full-size passes: tens of GB) go back to the driver when the module is done, so that
+    neither a later module nor a child process (tests/test_z_multirank_gpu.py) finds the GPU full of this process's cache."""
+    yield
+    if torch.cuda.is_available():
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 @pytest.fixture(scope="session")
 def gpu_device():
     if not torch.cuda.is_available():

@@ -1,6 +1,6 @@
 """GPU tests of the split-f16 ("f16x3") register-chain kernels (csrc/mcnerf_x3.h, mlp_x3_*.hip) against the fp32 CPU
 oracle: the fp32-GRADE mode (22-bit operands, three f16 MFMAs per product, fp32 accumulate), held to the same per-op
-bounds as the exact-fp32 kernels (tests/test_ops_gpu.py) - only summation order and the 2^-21 product rounding differ.
+bounds as the exact-fp32 kernels (tests/test_a_ops_gpu.py) - only summation order and the 2^-21 product rounding differ.
 """
 import math
 
