@@ -258,6 +258,57 @@ def parity_probe(precisions, dev):
     return out
 
 
+def compact_line(full, full_name="bench_full.json"):
+    """The ONE stdout line: bench.py's contract fields + roofline + cpu_baseline, and every secondary measurement of the full record
+    as a scalar (the fp32-grade `f16x3` mode beside the headline, the pinned-occupancy lines, N = 65536 / 7000, render)."""
+    sig = lambda v, n=5: (None if v is None else float(f"{v:.{n}g}"))
+    r = full["roofline"]
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline") if k in full}
+    line["value"], line["ms_per_step"] = sig(full["value"], 7), sig(full["ms_per_step"], 6)
+    line["dtype"] = full["dtype"].split(" (")[0]
+    line["data"] = full["data"]
+    c = full["config"]
+    line["config"] = {"workload": c["workload"], "precision": c["precision"], "rays_per_step_per_gpu": c["rays_per_step_per_gpu"],
+                      "fine_samples_per_ray": sig(c["fine_samples_per_ray"]), "parallelism": c["parallelism"].split(" (")[0]}
+    line["roofline"] = {"bound": r["bound"], "kernel": r["kernel"], "ms": sig(r["ms"]), "achieved": sig(r["achieved"]), "peak": r["peak"],
+                        "unit": r["unit"], "frac": sig(r["frac"]), "traffic": sig(r["traffic"]),
+                        "step_mfma_frac": sig(r["step_mfma_frac"]), "step_traffic_bytes": sig(r.get("step_traffic_bytes")),
+                        "algorithmic_bytes_per_step": r.get("algorithmic_bytes_per_step")}
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample"][:120], "render_value": sig(cb.get("render_value"))}
+    for p, rec in full.get("by_precision", {}).items():
+        line[f"{p}_value"], line[f"{p}_ms_per_step"] = sig(rec["value"]), sig(rec["ms_per_step"])
+        if p == "f16x3":
+            line["f16x3_step_mfma_frac"] = sig(rec.get("step_mfma_frac"))
+    head = full["config"]["precision"]
+    for rho, modes in full.get("by_occupancy", {}).items():
+        tag = "rho" + rho.replace("0.", "0").replace(".", "")
+        for p, rec in modes.items():
+            line[f"{tag}_value" if p == head else f"{tag}_{p}_value"] = sig(rec["value"])
+    ex = full.get("extra_lines", {})
+    for key, name in (("rays_65536", "n65536_value"), ("rays_7000", "n7000_value"), ("coarse_8x256x4", "coarse8x256_value"),
+                      ("reference_default_128x5_rays_7000", "ref128x5_n7000_value"), ("render", "render_value")):
+        if key in ex:
+            line[name] = sig(ex[key]["value"])
+    if "parity" in full:        # what the headline mode's arithmetic costs against the fp32 oracle (256 rays), beside f16x3 / f32
+        pr = full["parity"]
+        gp = {head: [sig(pr["grad_worst_rel_to_tensor_max"], 2), sig(pr["grad_median_rel_to_tensor_max"], 2)]}
+        for p in ("f16x3", "f32"):
+            if p in pr:
+                gp[p] = [sig(pr[p]["grad_worst_rel_to_tensor_max"], 2), sig(pr[p]["grad_median_rel_to_tensor_max"], 2)]
+        line["parity"] = {"rgb_max_abs_err": sig(max(pr["rgb_c_max_abs_err"], pr["rgb_f_max_abs_err"]), 2),
+                          "gradient_parity": gp, "what": "256 rays vs fp32 CPU oracle; gradients: [worst, median] tensor error / tensor max"}
+    for k in ("allreduce_ms", "params_identical_across_ranks", "asymmetric_grad_steps", "valid", "skipped_optimizer_steps"):
+        if k in full:
+            line[k] = full[k]
+    line["dist"] = full.get("dist")
+    line["full_record"] = full_name
+    return line
+
+
 def parse_net(text):
     """'8x256x4' -> (8, 256, [4]) (depth x width x skip layer; config/config.yaml:76-81)."""
     d, w, k = (int(t) for t in text.lower().split("x"))
@@ -549,6 +600,7 @@ def run_rank(args):
         extra["coarse_8x256x4"] = dict(ex(coarse=(8, 256, [4])), what="both nets 8x256/[4] (SURVEY 8: the variant reported beside the default); "
                                        "kernel_ms<256> averages the coarse and the fine call")
         extra["rays_7000"] = dict(ex(rays=7000), what="N = 7000, the reference's `batch` (config/config.yaml:30)")
+        extra["rays_65536"] = dict(ex(rays=65536), what="N = 65536, SURVEY 8(d)'s throughput batch (the default line is N = 32768)")
         extra["reference_default_128x5_rays_7000"] = dict(ex(rays=7000, samples=128, scale=5),
                                                           what="the reference's default sampling: 128 coarse x 5 (fine grid 640, random cap at 128 kept per ray), N = 7000")
         if world == 1:
@@ -598,11 +650,23 @@ def run_rank(args):
         for k in ("allreduce_ms", "rank_ms_per_step", "rank_allreduce_ms", "params_identical_across_ranks", "asymmetric_grad_steps", "finite", "skipped_optimizer_steps", "valid"):
             if k in head:
                 out[k] = head[k]
+        # the process group the numbers were taken on: `backend` "nccl" IS RCCL on ROCm (gloo only on the test rigs that share a GPU)
+        out["dist"] = {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
+                       "rccl_ranks": (world if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0)),
+                       "one_gpu_per_rank": os.environ.get("MCNERF_SHARE_GPU") != "1"}
         if world == 1 and not args.no_cpu_baseline:
             # (the default mode beside the mode whose every operand is 22-bit, and the exact-fp32 mode: the same probe in each)
             out["parity"] = parity_probe(list(dict.fromkeys([args.precision, "f16x3", "f32"])), dev)
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        # the whole record goes to a file; stdout gets ONE compact line (< 2 KB) that carries the contract's fields and the secondary
+        # lines as scalars -- the driver keeps the stdout line, and round 4's 8 KB line was cut in its record
+        for path in dict.fromkeys([args.full_json] + ([os.path.join("gpurun_out", "bench_full.json")] if os.path.isdir("gpurun_out") else [])):
+            try:
+                with open(path, "w") as fh:
+                    json.dump(out, fh)
+            except OSError as e:
+                print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+        print(json.dumps(compact_line(out, os.path.basename(args.full_json))))
         allrecs = [(args.precision, head)] + list(others.items()) + [(f"occupancy {o}/{p}", r) for o, d in by_occ.items() for p, r in d.items()] \
             + [(k, r) for k, r in extra.items() if "valid" in r]
         bad = [p for p, r in allrecs if not r["valid"]]
@@ -687,6 +751,7 @@ def main():
                          "16-bit operand modes with their own stated error")
     ap.add_argument("--also", default="f16x3,f16,bf16,f32", help="other precision modes measured in the same run (by_precision)")
     ap.add_argument("--mode", default="train", choices=["train", "render"])
+    ap.add_argument("--full-json", default=os.path.join(ROOT, "bench_full.json"), help="where rank 0 writes the whole record (stdout gets the compact line)")
     ap.add_argument("--selftest", action="store_true", help="rendezvous / launcher check only (no kernels; works on CPU)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:

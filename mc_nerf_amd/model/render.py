@@ -166,6 +166,12 @@ class RenderTrainFn(torch.autograd.Function):
     def backward(ctx, d_rgb_c, d_rgb_f, _d_depth):
         owner, model_c, model_f = ctx.owner, ctx.model_c, ctx.model_f
         st: RenderSettings = owner.settings
+        if getattr(ctx, "workspaces_given_back", False):
+            # retain_graph=True + a second backward: the saved-operand set went back to the pool after the first one and the next
+            # forward may already have overwritten it -- refuse instead of returning gradients of clobbered operands
+            raise ops._lib.McnerfError("RenderTrainFn.backward ran twice on one forward (retain_graph): its saved-operand workspaces were "
+                                  "returned to the pool by the first backward; run the forward again")
+        ctx.workspaces_given_back = True
         saved = ctx.saved_tensors
         rays_d, rays_o, jit, eps_c, barf_w, out_c, flat_c, packed_c = saved[:8]
         dev = rays_d.device

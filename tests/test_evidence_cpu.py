@@ -65,6 +65,26 @@ def test_bench_line_contract():
         assert d["by_precision"][p]["valid"] and d["by_precision"][p]["steps"] >= 20
 
 
+def test_compact_stdout_line_of_the_committed_record():
+    """bench.py prints compact_line(full record): < 2 KB, the contract's fields, roofline, cpu_baseline, and the secondary lines as
+    scalars -- above all the all-22-bit `f16x3` mode beside the headline (round 4's 8 KB line was cut in the driver's record)."""
+    import bench
+    path, d = _latest_default_line()
+    line = bench.compact_line(d)
+    text = json.dumps(line)
+    assert len(text) < 2048, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "f16x3_value", "f16x3_ms_per_step", "rho025_value", "rho005_value", "full_record"):
+        assert k in line, k
+    assert line["value"] == pytest.approx(d["value"], rel=1e-5) and line["dtype"] == d["config"]["precision"]
+    assert line["f16x3_value"] == pytest.approx(d["by_precision"]["f16x3"]["value"], rel=1e-3)
+    r = line["roofline"]
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3) and r["bound"] == "mfma"
+    assert set(line["parity"]["gradient_parity"]) >= {line["dtype"], "f16x3"}
+    if "rays_65536" in d["extra_lines"]:        # (round 5 on: SURVEY 8(d)'s throughput batch)
+        assert line["n65536_value"] > 0
+
+
 @pytest.mark.parametrize("precision", ["f16x3h", "f16x3", "f16"])
 def test_pmc_traffic_belongs_to_the_sources_in_the_tree(precision):
     import bench

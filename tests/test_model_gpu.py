@@ -794,6 +794,71 @@ def test_mc_model_step_matches_reference_golden(gpu_device, name, stage, opt_idx
         assert model.weights_pose.grad is None               # (main.py:199 freezes it; the forward detaches it: model/mc_nerf.py:87)
 
 
+@pytest.mark.parametrize("resident", [False, True])
+def test_mc_model_step_with_the_device_side_pixel_draw(gpu_device, resident):
+    """SURVEY 8 rows a2 / f3 inside the real step: `MC_Model.sample_pixels` is NOT replaced -- the device sampler draws the step's
+    pixels (model/mc_nerf.py:327-345: randperm(H*W)[:batch], gather d / o / gt at those ids) -- and what the step consumed is checked
+    against the definitions: `batch` distinct ids in [0, H*W); the rays handed to the renderer are the full-image rays
+    (`get_rays`, :124-145) at those ids; the ground truth in the loss is the image at those ids (host tensor of the reference's
+    loader, or the uint8 DeviceImageSet gather of row f3); torch's seed governs the draw (main.py:274-277); two steps draw two subsets."""
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd.data import DeviceImageSet
+    from mc_nerf_amd.model import MC_Model, MC_NeRF_Loss
+    g = load_golden("g11_mc_model_step")
+    dev = gpu_device
+    H, W, B, cam = int(g["H"]), int(g["W"]), int(g["B"]), int(g["cam"])
+    sp = S.make_sys_param(dev, samples=32, scale=2, batch=B, H=H, W=W, coarse=(4, 32, [2]), fine=(8, 64, [4]),
+                          barf_start=float(g["barf"][0]), barf_end=float(g["barf"][1]), precision="f16x3")
+    model = MC_Model(sp).to(dev)
+    model.load_state_dict({k[2:]: t(v) for k, v in g.items() if k.startswith("p.")})
+    if resident:
+        u8 = torch.randint(0, 256, (model.train_numb, H * W, 4), dtype=torch.uint8, generator=torch.Generator().manual_seed(5))
+        images = DeviceImageSet(u8.to(dev), H, W)
+        f = u8[cam].float() / 255.0
+        gt_full = (f[:, :3] * f[:, 3:] + (1 - f[:, 3:])).to(dev)          # data/data_read.py:130-137
+    else:
+        images = t(g["gt_img"])
+        gt_full = images.reshape(-1, 3).to(dev)
+    seen = {"ids": [], "rays": []}
+    draw, render = model.sample_pixels, model.nerf.render_rays_train
+
+    def spy_draw(npix):
+        ids = draw(npix)
+        seen["ids"].append(ids.clone())
+        return ids
+
+    def spy_render(d, o, e, r, only_coarse=False):
+        seen["rays"].append((d.detach().clone(), o.detach().clone()))
+        return render(d, o, e, r, only_coarse)
+    model.sample_pixels, model.nerf.render_rays_train = spy_draw, spy_render
+    data = (images, torch.tensor([cam]), t(g["wpts"]), t(g["pts"]), t(g["wpts_e"]), t(g["pts_e"]))
+
+    def step(seed):
+        torch.manual_seed(seed)
+        loss_dict, *_ = model(data, 20, "GLOBAL_OPTIM_EPOCH", float(g["cur_ratio"]))
+        return loss_dict
+    ld = step(11)
+    ids = seen["ids"][-1]
+    assert ids.dtype == torch.int64 and ids.shape == (B,) and ids.is_cuda
+    assert int(ids.min()) >= 0 and int(ids.max()) < H * W and ids.unique().numel() == B          # a subset WITHOUT replacement
+    assert torch.equal(ld["rgb"][2], gt_full[ids])                                                # gt[rand_idx] (:80)
+    with torch.no_grad():
+        kinv = model.intr_inv_adj if model.intr_inv_adj is not None else torch.linalg.inv(model.intr_adj)
+        d_all, o_all = model.get_rays(model.pose_adj, cam, kinv)
+    d, o = seen["rays"][-1]
+    assert err(d, d_all[ids].cpu().numpy()) < 2e-6 and err(o, o_all[ids].cpu().numpy()) < 2e-6    # rays_d[rand_idx], rays_o[rand_idx] (:340-342)
+    loss = MC_NeRF_Loss(sp)(ld, "GLOBAL_OPTIM_EPOCH")
+    loss.backward()
+    assert torch.isfinite(loss) and model.weights_pose.grad is not None and float(model.weights_pose.grad[cam].abs().max()) > 0
+    step(11)
+    assert torch.equal(seen["ids"][-1], ids)                        # the same seed draws the same pixels
+    step(12)
+    other = seen["ids"][-1]
+    assert not torch.equal(other, ids) and other.unique().numel() == B
+    both = torch.cat([ids, other]).unique().numel()                 # two independent subsets of B of H*W overlap in about B^2 / (H*W) ids
+    assert both > 2 * B - 4 * max(8, B * B // (H * W))
+
+
 def test_fused_radam_matches_reference_trajectory(gpu_device):
     from mc_nerf_amd.model import RAdam
     g = load_golden("g12_radam_loss")
@@ -1377,3 +1442,27 @@ def test_workspace_pool_reuses_the_step_workspaces(gpu_device):
     ref = m.nerf_fine.sigma[0].weight.grad
     # (the draws differ from call to call -- device RNG -- so only finiteness and the order of magnitude are comparable)
     assert torch.isfinite(g1).all() and torch.isfinite(ref).all() and float(g1.abs().max()) > 0.0
+
+
+def test_second_backward_through_a_retained_graph_is_refused(gpu_device):
+    """RenderTrainFn.backward hands its saved-operand set back to the pool; with retain_graph=True a second backward would read
+    operands the next forward may have overwritten and push the set into the pool twice.  It must raise, not return gradients."""
+    from mc_nerf_amd import synthetic as S
+    from mc_nerf_amd._lib import McnerfError
+    from mc_nerf_amd.model import MC_NeRF_Loss, NeRF_Model
+    dev = gpu_device
+    N = 256
+    sp = S.make_sys_param(dev, samples=32, scale=2, batch=N, H=32, W=32, coarse=(4, 32, [2]), fine=(8, 64, [4]), precision="f16x3")
+    torch.manual_seed(1)
+    m = NeRF_Model(sp).to(dev)
+    g = torch.Generator().manual_seed(2)
+    o = (torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1) * 3.0).to(dev)
+    d = torch.nn.functional.normalize(-o.cpu() + 0.3 * torch.randn(N, 3, generator=g), dim=-1).to(dev)
+    gt = torch.rand(N, 3, generator=g).to(dev)
+    rgb_c, rgb_f = m.render_rays_train(d, o, 0, 1.0)
+    loss = MC_NeRF_Loss(sp).get_rgb_loss([rgb_c, rgb_f, gt])
+    loss.backward(retain_graph=True)
+    n_free = sum(len(v) for v in m.ws_pool.free.values())
+    with pytest.raises(McnerfError, match="ran twice"):
+        loss.backward()
+    assert sum(len(v) for v in m.ws_pool.free.values()) == n_free          # nothing was pushed a second time

@@ -99,7 +99,7 @@ print("rccl-1-rank: OK")
 
 
 @pytest.mark.timeout(460)
-def test_bench_two_ranks_share_one_gpu(gpu_device):
+def test_bench_two_ranks_share_one_gpu(gpu_device, tmp_path):
     """`python bench.py --gpus 2` end to end on the one-GPU box: the parent starts two rank processes, they rendezvous (gloo here:
     RCCL needs one GPU per rank), shard the cameras, run the step loop with the gradient sync, and rank 0 prints the JSON line with
     the multi-rank fields -- parameters bit-identical across ranks, no asymmetric gradient step, the all-reduce time."""
@@ -108,11 +108,17 @@ def test_bench_two_ranks_share_one_gpu(gpu_device):
     env = dict(os.environ, MCNERF_SHARE_GPU="1", MCNERF_DIST_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
+    full = os.path.join(str(tmp_path), "bench_full.json")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rays", "2048", "--steps", "6", "--warmup", "2",
-                        "--also=", "--no-cpu-baseline"], capture_output=True, text=True, timeout=400, env=env)
+                        "--also=", "--no-cpu-baseline", "--full-json", full], capture_output=True, text=True, timeout=400, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
+    assert len(line) < 2048, len(line)                      # the stdout line the driver keeps is the compact one ...
+    c = json.loads(line)
+    assert c["n_gpus"] == 2 and c["dist"] == {"world_size": 2, "backend": "gloo", "rccl_ranks": 0, "one_gpu_per_rank": False}
+    assert c["params_identical_across_ranks"] is True and c["asymmetric_grad_steps"] == 0 and c["rho005_value"] > 0
+    j = json.load(open(full))                               # ... and the whole record is the file it names
+    assert c["full_record"] == "bench_full.json" and abs(j["value"] - c["value"]) < 1e-5 * j["value"]
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "weak"
     assert j["params_identical_across_ranks"] is True and j["asymmetric_grad_steps"] == 0 and j["finite"] is True
     assert j["allreduce_ms"] > 0 and j["value"] > 0
