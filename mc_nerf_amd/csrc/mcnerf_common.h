@@ -256,6 +256,49 @@ __device__ __forceinline__ void mcn_sincos(float v, float& s, float& c) {
     c = ((qi + 1) & 2) ? -b : b;
 }
 
+// sin / cos of 2^f v for f = 0 .. NF-1, every one within an fp32 rounding of the true value: the octave-0 pair in fp64 (the
+// reduction of mcn_sincos, Taylor kernels to x^13 / x^14 on [-pi/4, pi/4]: error < 1e-15), every further octave by the double-angle
+// step s' = 2 s c, c' = 1 - 2 s^2 IN FP64 -- 3 fp64 operations + 2 conversions per octave (fp64 FMAs issue at the fp32 rate on
+// gfx950) instead of a 9-operation fp64 reduction + two fp32 polynomials (~40 instructions) per octave.  Error growth: the
+// step doubles a phase error and turns a radius error into at most 4 x as much phase error; from 1e-16 roundings that is < 1e-12
+// after nine steps, against fp32's 6e-8.  (The 16-bit modes run the same recurrence in fp32, where it costs 3e-5 at 2^9.)
+// Per sample: 3 x (~35 + 9 x 5) ~ 240 instructions instead of 30 x ~40; stamps (scripts/stamps_x3.py): the encoding was 6.0 k
+// cycles of a 36 k (128-wide) / 193 k (256-wide) forward pass, and as much again in the backward.
+template <int NF>
+__device__ __forceinline__ void mcn_sincos_octaves(float v, float (&S)[NF], float (&C)[NF]) {
+    const double t = (double)v * 0.15915494309189535;         // turns
+    const double fr = t - __builtin_rint(t);                   // [-0.5, 0.5]
+    const double q = __builtin_rint(4.0 * fr);                 // nearest quarter turn: -2 .. 2
+    const double phi = (fr - 0.25 * q) * 6.283185307179586;    // [-pi/4, pi/4]
+    const double z = phi * phi;
+    double sp = __builtin_fma(z, 1.6059043836821613e-10, -2.505210838544172e-08);
+    sp = __builtin_fma(sp, z, 2.7557319223985893e-06);
+    sp = __builtin_fma(sp, z, -1.984126984126984e-04);
+    sp = __builtin_fma(sp, z, 8.333333333333333e-03);
+    sp = __builtin_fma(sp, z, -1.6666666666666666e-01);
+    sp = __builtin_fma(sp * z, phi, phi);
+    double cp = __builtin_fma(z, -1.1470745597729725e-11, 2.08767569878681e-09);
+    cp = __builtin_fma(cp, z, -2.755731922398589e-07);
+    cp = __builtin_fma(cp, z, 2.48015873015873e-05);
+    cp = __builtin_fma(cp, z, -1.388888888888889e-03);
+    cp = __builtin_fma(cp, z, 4.1666666666666664e-02);
+    cp = __builtin_fma(cp, z, -0.5);
+    cp = __builtin_fma(cp, z, 1.0);
+    const int qi = (int)q & 3;                                 // two's complement: -1 -> 3, -2 -> 2
+    const double a = (qi & 1) ? cp : sp, b = (qi & 1) ? sp : cp;
+    double s = (qi & 2) ? -a : a;                              // q=0: (s, c)  1: (c, -s)  2: (-s, -c)  3: (-c, s)
+    double c = ((qi + 1) & 2) ? -b : b;
+    S[0] = (float)s; C[0] = (float)c;
+#pragma unroll
+    for (int f = 1; f < NF; ++f) {
+        const double t2 = s + s;
+        const double sn = t2 * c;                              // sin 2a = 2 sin a cos a
+        c = __builtin_fma(-t2, s, 1.0);                        // cos 2a = 1 - 2 sin^2 a
+        s = sn;
+        S[f] = (float)s; C[f] = (float)c;
+    }
+}
+
 // The nine signed deg-2 SH basis factors of eval_sh (model/net_utils.py:154-169).
 __device__ __forceinline__ void mcn_sh_basis(float x, float y, float z, float (&b)[9]) {
     const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;

@@ -216,108 +216,22 @@ __device__ __forceinline__ unsigned mcnx3_frag_off(const Mcn16Ring& r, const Mcn
     return (next ? r.next_off : c.cur) + (f & (MCNX3_SLABF - 1)) * 2048;
 }
 
-// ---- the encoding ONCE PER SAMPLE, split over the two lane halves.  Both lanes (m, 0) and (m, 32) of a sample used to evaluate all
-// 30 sin / cos pairs (6.0 k cycles of a pass, scripts/stamps_x3.py) although half h only packs the channels c with bit 2 of c equal to h
-// (channel of (k-step s, half h, element j) = 16 s + 8 (j >> 2) + 4 h + (j & 3)).  Of the 30 (axis, octave) pairs, 7 feed only half 0
-// (sin channel 3 + 20 a + f and cos channel 13 + 20 a + f both have bit 2 clear), 8 only half 1, and 15 feed one value to each.
-// So each half evaluates 15 pairs -- its own and, per axis, enough of the shared ones to make five -- and hands the partner the one
-// value it needs of each shared pair it owns: 9 cross-half shuffles (three slots per axis) instead of 15 more sin / cos pairs.  The
-// plan below is compile-time; every index in the kernels is a constant after unrolling, the VALUES are those of the plain form.
-// Measured (same box, 4.19 M rows of the 4 x 128 net): saving forward 3.85 / 3.82 -> 3.77 / 3.76 ms, no-save forward 2.31 / 2.30 ->
-// 2.22 / 2.22 ms.  Used by the forward of nets up to 128 wide: the 256-wide instantiation (492 registers) spills with it, and the
-// same split of the backward's encoding gradient measured 0 % at width 128 (its pass is bound elsewhere) and spilled 28 registers
-// at 256 -- not kept there.
-#ifndef MCNX3_ENC_SPLIT_MAXW
-#define MCNX3_ENC_SPLIT_MAXW 128       // nets up to this width use the split evaluation (the 256-wide chains have no register to spare for it)
-#endif
-struct Mcnx3EncPlan {
-    int freq[2][15];      // octave of slot s (axis s / 5) of half h
-    int owner[30];        // pair k = 10 a + f: the half that evaluates it
-    int slot[30];         // ... in which of its slots
-    int xidx[30];         // shared pairs: the outgoing slot 3 a + j of the owner (-1: exclusive)
-    int send_sin[30];     // shared pairs: 1 = the partner needs the sine (the owner keeps the cosine), 0 = the cosine
-};
-__host__ __device__ constexpr int mcnx3_half_of(int ch) { return (ch >> 2) & 1; }
-__host__ __device__ constexpr Mcnx3EncPlan mcnx3_enc_plan() {
-    Mcnx3EncPlan P{};
-    for (int a = 0; a < 3; ++a) {
-        int n[2] = {0, 0}, nx[2] = {0, 0};
-        // exclusive pairs first
-        for (int f = 0; f < MCN_NFREQ; ++f) {
-            const int k = 10 * a + f, hs = mcnx3_half_of(3 + 20 * a + f), hc = mcnx3_half_of(13 + 20 * a + f);
-            P.xidx[k] = -1; P.send_sin[k] = -1;
-            if (hs == hc) { P.owner[k] = hs; P.slot[k] = 5 * a + n[hs]; P.freq[hs][5 * a + n[hs]] = f; ++n[hs]; }
-        }
-        // shared pairs: half 0 fills up to five, half 1 takes the rest
-        for (int f = 0; f < MCN_NFREQ; ++f) {
-            const int k = 10 * a + f, hs = mcnx3_half_of(3 + 20 * a + f), hc = mcnx3_half_of(13 + 20 * a + f);
-            if (hs == hc) continue;
-            const int o = n[0] < 5 ? 0 : 1;
-            P.owner[k] = o; P.slot[k] = 5 * a + n[o]; P.freq[o][5 * a + n[o]] = f; ++n[o];
-            P.xidx[k] = 3 * a + nx[o]; ++nx[o];
-            P.send_sin[k] = (hs == 1 - o) ? 1 : 0;           // the partner holds the sine channel -> it needs the sine
-        }
-    }
-    return P;
-}
-static constexpr Mcnx3EncPlan MCNX3_ENC = mcnx3_enc_plan();
-
-// The 63 (+1 pad) encoded channels of one sample, fp32-accurate: sin / cos of 2^f x by an fp64 range reduction per
-// octave (mcn_sincos), times the BARF weight of f (model/net_block.py:22-33 order: x, y, z, then per axis sin f = 0..9, cos f = 0..9).
+// The 63 (+1 pad) encoded channels of one sample, each sin / cos within an fp32 rounding of the true value: one fp64 sin / cos per
+// axis, the octaves by the fp64 double-angle step (mcn_sincos_octaves: ~240 instructions per sample instead of 30 fp64 reductions +
+// fp32 polynomials = ~1200; round 4 had halved those 30 by splitting them over a sample's two lanes, at the price of 9 shuffles and of
+// registers the 256-wide chains did not have -- the recurrence is cheaper than that split on every width and needs neither), times
+// the BARF weight of f (model/net_block.py:22-33 order: x, y, z, then per axis sin f = 0..9, cos f = 0..9).
 __device__ __forceinline__ void mcnx3_encode_values(const float (&p)[3], const float (&bw)[MCN_NFREQ], float (&E)[64]) {
     E[0] = p[0]; E[1] = p[1]; E[2] = p[2]; E[63] = 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
+        float S[MCN_NFREQ], C[MCN_NFREQ];
+        mcn_sincos_octaves<MCN_NFREQ>(p[a], S, C);
 #pragma unroll
         for (int f = 0; f < MCN_NFREQ; ++f) {
-            float s, c;
-            mcn_sincos(p[a] * (float)(1 << f), s, c);          // exact: power-of-two scale
-            E[3 + 20 * a + f] = s * bw[f];
-            E[3 + 20 * a + 10 + f] = c * bw[f];
+            E[3 + 20 * a + f] = S[f] * bw[f];
+            E[3 + 20 * a + 10 + f] = C[f] * bw[f];
         }
     }
-}
-// The lane's (hi, lo) encoded-input fragments, four k-steps: position (s, d) packs channels c(s, h, 2d) and c(s, h, 2d + 1).  The
-// values are those of mcnx3_encode_values (same sin / cos arguments, same BARF products); each half evaluates 15 of the 30 pairs.
-__device__ __forceinline__ void mcnx3_encode_frags(const float (&p)[3], const float (&bw)[MCN_NFREQ], int h,
-                                                   u32x4_t (&ench)[MCN16_ENCKS], u32x4_t (&encl)[MCN16_ENCKS]) {
-    float S[15], C[15], OUT[9], IN[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) OUT[i] = 0.f;
-#pragma unroll
-    for (int sl = 0; sl < 15; ++sl) {
-        const int f0 = MCNX3_ENC.freq[0][sl], f1 = MCNX3_ENC.freq[1][sl];
-        const float scale = h ? (float)(1 << f1) : (float)(1 << f0), w = h ? bw[f1] : bw[f0];
-        float s_, c_;
-        mcn_sincos(p[sl / 5] * scale, s_, c_);               // exact: power-of-two scale
-        S[sl] = s_ * w; C[sl] = c_ * w;
-    }
-    // outgoing values of the shared pairs (slot 3 a + j): both directions travel in one shuffle per slot
-#pragma unroll
-    for (int k = 0; k < 30; ++k) {
-        if (MCNX3_ENC.xidx[k] < 0) continue;
-        const float v = MCNX3_ENC.send_sin[k] ? S[MCNX3_ENC.slot[k]] : C[MCNX3_ENC.slot[k]];
-        OUT[MCNX3_ENC.xidx[k]] = (h == MCNX3_ENC.owner[k]) ? v : OUT[MCNX3_ENC.xidx[k]];
-    }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) IN[i] = __shfl_xor(OUT[i], 32);
-    // a channel's value as the half that packs it sees it (that half = bit 2 of the channel)
-    auto val = [&](int ch) -> float {
-        if (ch < 3) return p[ch];
-        if (ch >= MCN_ENC) return 0.f;
-        const int a = (ch - 3) / 20, r = (ch - 3) - 20 * a, k = 10 * a + r % 10;
-        if (MCNX3_ENC.owner[k] == mcnx3_half_of(ch)) return r < 10 ? S[MCNX3_ENC.slot[k]] : C[MCNX3_ENC.slot[k]];
-        return IN[MCNX3_ENC.xidx[k]];
-    };
-#pragma unroll
-    for (int s = 0; s < MCN16_ENCKS; ++s)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int c0 = mcn16_chan(s, 0, 2 * d), c1 = mcn16_chan(s, 0, 2 * d + 1);
-            const float v0 = h ? val(c0 + 4) : val(c0), v1 = h ? val(c1 + 4) : val(c1);
-            unsigned wh, wl;
-            mcnx3_split2(v0 * MCNX3_SX, v1 * MCNX3_SX, wh, wl);
-            ench[s][d] = wh; encl[s][d] = wl;
-        }
 }
 #endif

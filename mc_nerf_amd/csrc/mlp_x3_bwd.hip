@@ -478,13 +478,13 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
                 float acc = dch(ax);
+                float S[MCN_NFREQ], C[MCN_NFREQ];
+                mcn_sincos_octaves<MCN_NFREQ>(p[ax], S, C);       // (the forward's values: mcnerf_x3.h)
 #pragma unroll
                 for (int f = 0; f < MCN_NFREQ; ++f) {
-                    float s, c;
-                    mcn_sincos(p[ax] * (float)(1 << f), s, c);
                     const float k = (float)(1 << f) * sbarf[f];
-                    acc = fmaf(k * c, dch(3 + 20 * ax + f), acc);
-                    acc = fmaf(-k * s, dch(3 + 20 * ax + 10 + f), acc);
+                    acc = fmaf(k * C[f], dch(3 + 20 * ax + f), acc);
+                    acc = fmaf(-k * S[f], dch(3 + 20 * ax + 10 + f), acc);
                 }
                 dpos[ax] = acc * (1.0f / MCNX3_SW);
             }

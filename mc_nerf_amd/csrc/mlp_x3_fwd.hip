@@ -292,9 +292,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         }
         const int addr = ray * a.S + j;
         u32x4_t ench[MCN16_ENCKS], encl[MCN16_ENCKS];
-        if constexpr (W <= MCNX3_ENC_SPLIT_MAXW) {
-            mcnx3_encode_frags(p, bw, h, ench, encl);     // (each lane half evaluates 15 of the sample's 30 sin / cos pairs: mcnerf_x3.h)
-        } else {   // the 256-wide instantiation has no register to spare: the split form spills there (4 VGPRs), the plain one does not
+        {
             float E[64];
             mcnx3_encode_values(p, bw, E);
 #pragma unroll
