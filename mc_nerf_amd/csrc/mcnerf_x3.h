@@ -18,7 +18,9 @@
 #pragma once
 #include "mcnerf_16.h"
 
+#ifndef MCNX3_SW
 #define MCNX3_SW 256.0f
+#endif
 #define MCNX3_SX 8.0f
 #define MCNX3_SLABF 8                  // logical fragments (hi + lo piece) per ring slab
 #ifndef MCNX3_PF

@@ -260,7 +260,11 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         }
     };
     auto buf_of = [&](int slot) { return (D + 1 - slot) % 3; };
+#ifdef ABLX3_MASKL2      // (timing-only ablation: every pass reads the same few mask tiles = the reads hit in L2)
+    auto mask_lane_of = [&](long long pass_) { return a.mask_ws + ((size_t)((pass_ & 1) * WAVES + wave) * 64 + lane) * MW; };
+#else
     auto mask_lane_of = [&](long long pass_) { return a.mask_ws + ((size_t)(pass_ * WAVES + wave) * 64 + lane) * MW; };
+#endif
     unsigned mk0_s[MW], mk0_c[MW], mk0_t[MW];                  // (narrow nets) the first three slots of the coming pass
     {
         const unsigned* ml0 = mask_lane_of(blockIdx.x);
@@ -273,8 +277,12 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         const long long tile = pass * WAVES + wave;
         const long long g = tile * 32 + m;
         const bool valid = g < total;
-        const unsigned* mask_lane = a.mask_ws + ((size_t)tile * 64 + lane) * MW;
+        const unsigned* mask_lane = mask_lane_of(pass);
+#ifdef ABLX3_STOREWIN    // (timing-only ablation: every pass writes the same few tiles = the stores issue but stay in cache)
+        char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)(tile & 3) * (PL * KS) * 1024 + lane * 16;
+#else
         char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)tile * (PL * KS) * 1024 + lane * 16;
+#endif
         // ---- per-sample prologue (lane-local): sigmoid and SH backward
         if (PREFB) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_TOP) : "memory");       // (the first pass: vmcnt(0) was waited for below the mask prefetch)
@@ -347,7 +355,11 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         if (PREFB && want_rays) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
+#ifdef ABLX3_SHSL2       // (timing-only ablation: the saved sh.2 outputs from the same few tiles)
+                shs[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)(tile & 7) * 4096 + q * 1024 + lane * 16);
+#else
                 shs[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 4096 + q * 1024 + lane * 16);
+#endif
         }
         u32x4_t xah[KS], xal[KS], xbh[KS], xbl[KS];
         f32x16 denc[2];

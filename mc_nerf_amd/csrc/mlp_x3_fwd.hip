@@ -305,7 +305,11 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
                     ench[s][d] = wh; encl[s][d] = wl;
                 }
         }
+#ifdef ABLX3_STOREWIN    // (timing-only ablation: every pass writes the same few tiles = the stores issue but stay in cache)
+        char* act_lane = SAVE ? reinterpret_cast<char*>(a.act_ws) + (size_t)(tile & 3) * (PL * KS) * 1024 + lane * 16 : nullptr;
+#else
         char* act_lane = SAVE ? reinterpret_cast<char*>(a.act_ws) + (size_t)tile * (PL * KS) * 1024 + lane * 16 : nullptr;
+#endif
         unsigned* mask_lane = SAVE ? a.mask_ws + ((size_t)tile * 64 + lane) * MW : nullptr;
         if (SAVE) {
             char* e = reinterpret_cast<char*>(a.enc_ws) + (size_t)tile * (PL * MCN16_ENCKS) * 1024 + lane * 16;

@@ -6,7 +6,8 @@ TAG=${1:-r04}
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python3 bench.py --steps 50 --warmup 5 2> gpurun_out/${TAG}_bench_default.err | tail -1 > gpurun_out/${TAG}_bench_default.json
+# (stdout = the compact line the driver keeps; --full-json = the whole record, committed as profiles/<tag>_bench_default.json)
+python3 bench.py --steps 50 --warmup 5 --full-json gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err | tail -1 > gpurun_out/${TAG}_bench_default_line.json
 for P in f16x3h f16x3 f16; do
   scripts/prof_bench.sh ${TAG}_$P --steps 10 --warmup 3 --also= --occupancy= --no-extra --no-cpu-baseline --precision $P > gpurun_out/${TAG}_kernel_table_$P.txt 2>&1
   cp gpurun_out/prof_${TAG}_$P/kernel_stats.csv gpurun_out/${TAG}_kernel_stats_$P.csv

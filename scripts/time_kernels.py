@@ -11,6 +11,8 @@ width = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 S = 128
 dev = torch.device("cuda:0")
 net, flat = make_net(width, dev)
+if os.environ.get('WSCALE'):          # (power experiments: the weights scaled by a factor, 0 = all-zero operands)
+    flat.mul_(float(os.environ['WSCALE']))
 g = torch.Generator(device=dev).manual_seed(0)
 o = torch.nn.functional.normalize(torch.randn(N, 3, device=dev, generator=g), dim=-1) * 3
 d = torch.nn.functional.normalize(-o + 0.5 * torch.randn(N, 3, device=dev, generator=g), dim=-1)

@@ -129,6 +129,28 @@ def test_bench_two_ranks_share_one_gpu(gpu_device, tmp_path):
             assert abs(rec["selected_fraction"] - float(rho)) < 0.5 * float(rho), (rho, p, rec["selected_fraction"])
 
 
+@pytest.mark.timeout(460)
+def test_bench_under_torchrun_with_one_rank_is_the_plain_line(gpu_device, tmp_path):
+    """The driver's N = 1 forms: `python bench.py` and `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` must be
+    the SAME path (no process group, no collective, no camera sharding) and report themselves so: n_gpus 1, dist.world_size 1,
+    rccl_ranks 1, parallelism dp1 -- and agree on the step time to the run-to-run spread of a 2048-ray step."""
+    import json
+    args = ["--gpus", "1", "--rays", "2048", "--steps", "20", "--warmup", "5", "--also=", "--occupancy=", "--no-extra", "--no-cpu-baseline"]
+    recs = []
+    for k, launcher in enumerate(([sys.executable], [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                                                     "--master-addr", "127.0.0.1", "--master-port", str(_free_port())])):
+        full = os.path.join(str(tmp_path), f"full{k}.json")
+        r = subprocess.run(launcher + [os.path.join(ROOT, "bench.py")] + args + ["--full-json", full], capture_output=True, text=True,
+                           timeout=400, env=_clean_env())
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        c = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert c["n_gpus"] == 1 and c["dist"]["world_size"] == 1 and c["dist"]["rccl_ranks"] == 1 and c["config"]["parallelism"] == "dp1"
+        assert "allreduce_ms" not in c and c["valid"] is True
+        recs.append(c)
+    a, b = recs[0]["ms_per_step"], recs[1]["ms_per_step"]
+    assert abs(a - b) < 0.15 * max(a, b), (a, b)          # (a 2048-ray step is ~2.5 ms, host-bound: the spread is the host's)
+
+
 @pytest.mark.timeout(420)
 def test_two_ranks_share_one_gpu_data_parallel(gpu_device):
     """N > 1 path with the real HIP backward: two gloo ranks on one GPU (scripts/two_rank_one_gpu.py) - the arena
