@@ -91,10 +91,12 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
             } else if (ph == IPW - 1) {
                 outl[2 * t + (p >> 2)][p & 3] = Mcn16T<false>::pack(mcnx3_residual<0>(v0, wkeep), mcnx3_residual<1>(v1, wkeep));
             } else {
+#ifndef ABLX3_NOMASK       // (timing-only: the ReLU bit words are not computed)
                 if (SAVE) {
                     mb = (p == 0) ? mcn16_nz(wkeep) : ((mb << 1) | mcn16_nz(wkeep));
                     if (p == 7) mw[t >> 1] |= mb << (8 * (t & 1));
                 }
+#endif
                 if (EPI == 1) {
                     const f32x2_t ww = *reinterpret_cast<const f32x2_t*>(w2_h + 32 * t + 8 * (p >> 1) + 2 * (p & 1));
                     dot = fmaf(v0, ww[0], dot);
