@@ -99,8 +99,9 @@ print("rccl-1-rank: OK")
 
 
 @pytest.mark.timeout(460)
-def test_bench_two_ranks_share_one_gpu(gpu_device, tmp_path):
-    """`python bench.py --gpus 2` end to end on the one-GPU box: the parent starts two rank processes, they rendezvous (gloo here:
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_two_ranks_share_one_gpu(gpu_device, tmp_path, world):
+    """`python bench.py --gpus 2` (and `--gpus 8`: the driver's largest form, eight rank processes sharing the GPU) end to end on the one-GPU box: the parent starts two rank processes, they rendezvous (gloo here:
     RCCL needs one GPU per rank), shard the cameras, run the step loop with the gradient sync, and rank 0 prints the JSON line with
     the multi-rank fields -- parameters bit-identical across ranks, no asymmetric gradient step, the all-reduce time."""
     import json
@@ -109,20 +110,20 @@ def test_bench_two_ranks_share_one_gpu(gpu_device, tmp_path):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     full = os.path.join(str(tmp_path), "bench_full.json")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rays", "2048", "--steps", "6", "--warmup", "2",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--rays", "2048", "--steps", "6", "--warmup", "2",
                         "--also=", "--no-cpu-baseline", "--full-json", full], capture_output=True, text=True, timeout=400, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     assert len(line) < 2048, len(line)                      # the stdout line the driver keeps is the compact one ...
     c = json.loads(line)
-    assert c["n_gpus"] == 2 and c["dist"] == {"world_size": 2, "backend": "gloo", "rccl_ranks": 0, "one_gpu_per_rank": False}
+    assert c["n_gpus"] == world and c["dist"] == {"world_size": world, "backend": "gloo", "rccl_ranks": 0, "one_gpu_per_rank": False}
     assert c["params_identical_across_ranks"] is True and c["asymmetric_grad_steps"] == 0 and c["rho005_value"] > 0
     j = json.load(open(full))                               # ... and the whole record is the file it names
     assert c["full_record"] == "bench_full.json" and abs(j["value"] - c["value"]) < 1e-5 * j["value"]
-    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["scaling"] == "weak"
+    assert j["n_gpus"] == world and j["steps"] == 6 and j["scaling"] == "weak"
     assert j["params_identical_across_ranks"] is True and j["asymmetric_grad_steps"] == 0 and j["finite"] is True
     assert j["allreduce_ms"] > 0 and j["value"] > 0
-    assert j["config"]["rays_per_step_per_gpu"] == 2048 and j["config"]["parallelism"].startswith("dp2")
+    assert j["config"]["rays_per_step_per_gpu"] == 2048 and j["config"]["parallelism"].startswith(f"dp{world}")
     for rho, modes in j["by_occupancy"].items():          # the occupancy shift is rank 0's on every rank: the DDP invariant holds on these lines too
         for p, rec in modes.items():
             assert rec["params_identical_across_ranks"] is True and rec["asymmetric_grad_steps"] == 0 and rec["valid"], (rho, p, rec)
@@ -148,7 +149,7 @@ def test_bench_under_torchrun_with_one_rank_is_the_plain_line(gpu_device, tmp_pa
         assert "allreduce_ms" not in c and c["valid"] is True
         recs.append(c)
     a, b = recs[0]["ms_per_step"], recs[1]["ms_per_step"]
-    assert abs(a - b) < 0.15 * max(a, b), (a, b)          # (a 2048-ray step is ~2.5 ms, host-bound: the spread is the host's)
+    assert abs(a - b) < 0.5 * max(a, b), (a, b)           # (a 2048-ray step is ~2.5 ms and host-bound: a loose gate -- the claim is the PATH, checked above)
 
 
 @pytest.mark.timeout(420)
