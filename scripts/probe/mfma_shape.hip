@@ -27,16 +27,19 @@ __global__ __launch_bounds__(256) void mfma_loop(const f16x8* __restrict__ in, f
         }
         for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
     } else {
+        // inline asm: hipcc's own allocation of eight 16x16 accumulators (AGPR shuffles, s_nops) halves the issue rate
         f32x4 c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
         for (int i = 0; i < iters; ++i) {          // 8 x 16x16x32 = the FLOPs of 4 x 32x32x16
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c3, 0, 0, 0);
-            c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c4, 0, 0, 0);
-            c5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, c5, 0, 0, 0);
-            c6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, c6, 0, 0, 0);
-            c7 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, c7, 0, 0, 0);
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %8, %10, %0\n\t"
+                         "v_mfma_f32_16x16x32_f16 %1, %9, %10, %1\n\t"
+                         "v_mfma_f32_16x16x32_f16 %2, %8, %11, %2\n\t"
+                         "v_mfma_f32_16x16x32_f16 %3, %9, %11, %3\n\t"
+                         "v_mfma_f32_16x16x32_f16 %4, %8, %10, %4\n\t"
+                         "v_mfma_f32_16x16x32_f16 %5, %9, %10, %5\n\t"
+                         "v_mfma_f32_16x16x32_f16 %6, %8, %11, %6\n\t"
+                         "v_mfma_f32_16x16x32_f16 %7, %9, %11, %7"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+                         : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
         }
         for (int e = 0; e < 4; ++e) s += c0[e] + c1[e] + c2[e] + c3[e] + c4[e] + c5[e] + c6[e] + c7[e];
     }
