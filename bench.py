@@ -49,6 +49,13 @@ ALGO_BYTES_PER_RAY = 100
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0      # ibid., "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0              # ibid., "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
+# The two unit costs of DESIGN.md 3.6's energy budget, measured on this pool (NOT vendor figures): what a bare
+# v_mfma_f32_32x32x16_f16 loop sustains on random operands under the chip's power management (profiles/r05k_mfma_shape.txt,
+# r05_mfma_peak.txt: 1.71-1.74 PF/s), and what a gigabyte written by a chain costs at unchanged cycle counts (saving minus
+# no-save forward: 1.6 ms for 18.3 GB in f16x3h, 1.6 ms for 18.1 GB in f16; profiles/r05f_ablate_storewin.txt, r05_cfg5_bf16_spread.txt)
+BARE_MFMA_TFLOPS_RANDOM = 1720.0
+CHAIN_WRITE_MS_PER_GB = 0.085
+MFMAS_PER_PRODUCT = {"f16x3h": (3, 3, 1), "f16x3": (3, 3, 3), "f16": (1, 1, 1), "bf16": (1, 1, 1)}      # forward chain, dX chain, weight gradient
 # HBM bytes per evaluated fine sample that each kernel's CONTRACT makes it move.
 #  fp32 / split-f16 words: 10 layer slots x 256 x 4 B (+ encoding 256, SH 128, 1-bit masks 320, output 16, index 8)
 B32 = {"fwd": 10 * 1024 + 256 + 128 + 320 + 16 + 8,
@@ -274,7 +281,8 @@ def compact_line(full, full_name="bench_full.json"):
     line["roofline"] = {"bound": r["bound"], "kernel": r["kernel"], "ms": sig(r["ms"]), "achieved": sig(r["achieved"]), "peak": r["peak"],
                         "unit": r["unit"], "frac": sig(r["frac"]), "traffic": sig(r["traffic"]),
                         "step_mfma_frac": sig(r["step_mfma_frac"]), "step_traffic_bytes": sig(r.get("step_traffic_bytes")),
-                        "algorithmic_bytes_per_step": r.get("algorithmic_bytes_per_step")}
+                        "algorithmic_bytes_per_step": r.get("algorithmic_bytes_per_step"),
+                        "design_floor_over_measured": sig((r.get("design_floor") or {}).get("floor_over_measured"), 3)}
     if "cpu_baseline" in full:
         cb = full["cpu_baseline"]
         line["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
@@ -539,6 +547,35 @@ def pmc_traffic(precision, kernel_key):
     return None, None
 
 
+def design_floor(precision, head, k_mean, rays, samples, coarse):
+    """the floor THIS design has on this chip -- the chains' executed MFMA work at the bare loop's rate + their PMC-measured
+    written bytes at the measured cost per gigabyte + the (HBM-bound) weight-gradient kernels and everything else as measured in this
+    run.  None without a PMC recording of the current kernel sources, and for the exact-fp32 mode (other instructions)."""
+    m = MFMAS_PER_PRODUCT.get(precision)
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{precision}.json")
+    if m is None or not os.path.isfile(path):
+        return None
+    rec = json.load(open(path))
+    if rec.get("csrc_digest") != csrc_digest():
+        return None
+    alg = (F_FINE * k_mean + net_flops(coarse) * rays * samples) / 1e12                 # algorithmic TFLOP of one kernel family
+    chain_tflop = (m[0] + m[1]) * alg
+    written = sum(v.get("write_bytes", 0.0) for k, v in rec["kernels"].items() if "mlp" in k and ("fwd_kernel" in k or "bwd_kernel" in k))
+    km = head["kernel_ms"]
+    dw_ms = sum(v for k, v in km.items() if k.startswith("mlp_dw"))
+    mlp_ms = sum(km.values())
+    other_ms = max(0.0, head["ms_per_step"] - mlp_ms)
+    chain_ms = chain_tflop / BARE_MFMA_TFLOPS_RANDOM * 1e3
+    write_ms = CHAIN_WRITE_MS_PER_GB * written / 1e9
+    floor = chain_ms + write_ms + dw_ms + other_ms
+    return {"chains_executed_tflop": chain_tflop, "chains_mfma_ms": chain_ms, "chains_written_GB": written / 1e9, "chains_write_ms": write_ms,
+            "dw_measured_ms": dw_ms, "other_measured_ms": other_ms, "floor_ms": floor, "measured_ms": head["ms_per_step"],
+            "measured_over_floor": head["ms_per_step"] / floor, "floor_over_measured": floor / head["ms_per_step"],
+            "what": "builder's energy budget of the step (DESIGN.md 3.6), NOT the contract's roofline: executed MFMA work of the chains at "
+                    f"{BARE_MFMA_TFLOPS_RANDOM:.0f} TFLOP/s (bare loop, random operands, this pool) + their written bytes at {CHAIN_WRITE_MS_PER_GB} ms/GB "
+                    "+ the HBM-bound weight-gradient kernels and the small kernels as measured"}
+
+
 def pmc_step_traffic(precision):
     """Sum of the PMC-measured HBM bytes of all six MLP kernels of a step from the same committed recording (None when stale)."""
     path = os.path.join(ROOT, "profiles", f"pmc_traffic_{precision}.json")
@@ -631,7 +668,8 @@ def run_rank(args):
                 "algorithmic_bytes_per_step": head["algorithmic_bytes_per_step"],
                 "step_traffic_bytes": step_traffic,
                 "traffic_over_algorithmic": (step_traffic / head["algorithmic_bytes_per_step"]) if step_traffic else None,
-                "per_call": pc, "step_algorithmic_tflop": head["step_algorithmic_tflop"], "step_mfma_frac": head["step_mfma_frac"]}
+                "per_call": pc, "step_algorithmic_tflop": head["step_algorithmic_tflop"], "step_mfma_frac": head["step_mfma_frac"],
+                "design_floor": design_floor(args.precision, head, k_mean, args.rays, args.samples, parse_net(args.coarse)) if default_shape else None}
         out = {
             "metric": "train rays/sec (coarse+fine, 64+128 samples)", "value": head["value"], "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],

@@ -96,3 +96,21 @@ def test_pmc_traffic_belongs_to_the_sources_in_the_tree(precision):
         pytest.skip("profiles/pmc_traffic_*.json was recorded at other kernel sources: re-run scripts/pmc_bench.sh on the GPU box")
     traffic, src = bench.pmc_traffic(precision, "mlp_dw<256>")
     assert traffic and traffic > 1e9 and rec["csrc_digest"] in src
+
+
+def test_design_floor_of_the_committed_record():
+    """`roofline.design_floor`: the budget is the sum of its parts, built from this run's own kernel times and the
+    PMC-written bytes, and it stays BELOW the measured step (a floor that a measurement beats is a wrong floor)."""
+    import bench
+    path, d = _latest_default_line()
+    f = d["roofline"].get("design_floor")
+    if f is None:
+        pytest.skip("record made without a PMC recording of its kernel sources")
+    assert f["floor_ms"] == pytest.approx(f["chains_mfma_ms"] + f["chains_write_ms"] + f["dw_measured_ms"] + f["other_measured_ms"])
+    assert f["chains_mfma_ms"] == pytest.approx(f["chains_executed_tflop"] / bench.BARE_MFMA_TFLOPS_RANDOM * 1e3)
+    assert f["chains_write_ms"] == pytest.approx(bench.CHAIN_WRITE_MS_PER_GB * f["chains_written_GB"])
+    assert f["measured_ms"] == pytest.approx(d["ms_per_step"]) and 0.5 < f["floor_over_measured"] < 1.0
+    k = d["config"]["fine_samples_per_ray"] * d["config"]["rays_per_step_per_gpu"]
+    mf, mb, _ = bench.MFMAS_PER_PRODUCT[d["config"]["precision"]]
+    assert f["chains_executed_tflop"] == pytest.approx((mf + mb) * (bench.F_FINE * k + bench.F_COARSE * 32768 * 64) / 1e12, rel=1e-6)
+    assert bench.compact_line(d)["roofline"]["design_floor_over_measured"] == pytest.approx(f["floor_over_measured"], rel=2e-3)
