@@ -90,7 +90,18 @@ __device__ __forceinline__ float mcnx3_relu(float x) {       // integer max: no 
     return __builtin_bit_cast(float, i > 0 ? i : 0);
 }
 __device__ __forceinline__ f32x16 mcnx3_mfma(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
+#ifdef ABLX3_MFMA16     // (timing-only, results INVALID: the same MACs and pipe time as TWO v_mfma_f32_16x16x32_f16 on two quarters of the
+    //                     accumulator -- what the other MFMA shape would cost / save inside the real instruction stream: DESIGN.md 3.6)
+    typedef float f32x4m __attribute__((ext_vector_type(4)));
+    f32x4m c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c1, 0, 0, 0);
+    f32x16 r = c;
+    r[0] = c0[0]; r[1] = c0[1]; r[2] = c0[2]; r[3] = c0[3]; r[4] = c1[0]; r[5] = c1[1]; r[6] = c1[2]; r[7] = c1[3];
+    return r;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+#endif
 }
 // acc += (ah + al) (bh + bl) without the lo * lo term; smallest terms first
 __device__ __forceinline__ void mcnx3_mfma3(f32x16& acc, const u32x4_t& ah, const u32x4_t& al, const u32x4_t& bh, const u32x4_t& bl) {
