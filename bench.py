@@ -281,8 +281,7 @@ def compact_line(full, full_name="bench_full.json"):
     line["roofline"] = {"bound": r["bound"], "kernel": r["kernel"], "ms": sig(r["ms"]), "achieved": sig(r["achieved"]), "peak": r["peak"],
                         "unit": r["unit"], "frac": sig(r["frac"]), "traffic": sig(r["traffic"]),
                         "step_mfma_frac": sig(r["step_mfma_frac"]), "step_traffic_bytes": sig(r.get("step_traffic_bytes")),
-                        "algorithmic_bytes_per_step": r.get("algorithmic_bytes_per_step"),
-                        "design_floor_over_measured": sig((r.get("design_floor") or {}).get("floor_over_measured"), 3)}
+                        "algorithmic_bytes_per_step": r.get("algorithmic_bytes_per_step")}
     if "cpu_baseline" in full:
         cb = full["cpu_baseline"]
         line["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
@@ -309,11 +308,36 @@ def compact_line(full, full_name="bench_full.json"):
                 gp[p] = [sig(pr[p]["grad_worst_rel_to_tensor_max"], 2), sig(pr[p]["grad_median_rel_to_tensor_max"], 2)]
         line["parity"] = {"rgb_max_abs_err": sig(max(pr["rgb_c_max_abs_err"], pr["rgb_f_max_abs_err"]), 2),
                           "gradient_parity": gp, "what": "256 rays vs fp32 CPU oracle; gradients: [worst, median] tensor error / tensor max"}
-    for k in ("allreduce_ms", "params_identical_across_ranks", "asymmetric_grad_steps", "valid", "skipped_optimizer_steps"):
+    for k in ("allreduce_ms", "rank_ms_per_step", "params_identical_across_ranks", "asymmetric_grad_steps", "valid", "skipped_optimizer_steps"):
         if k in full:
-            line[k] = full[k]
+            v = full[k]["all"] if isinstance(full[k], dict) and "all" in full[k] else full[k]      # (rank_ms_per_step: every rank's own time)
+            line[k] = [sig(x, 4) for x in v] if isinstance(v, (list, tuple)) else (sig(v, 4) if isinstance(v, float) else v)
     line["dist"] = full.get("dist")
     line["full_record"] = full_name
+    return fit_line(line)
+
+
+COMPACT_LINE_BUDGET = 1900      # bytes of the stdout line (the driver's record keeps 2 KB of it)
+# what goes first when the line is over budget: secondary scalars (every one of them is in the full record), then the long strings
+DROP_ORDER = ("ref128x5_n7000_value", "coarse8x256_value", "n7000_value", "render_value", "f32_ms_per_step", "bf16_ms_per_step",
+              "f16_ms_per_step", "rho025_f16_value", "rho005_f16_value", "f32_value", "bf16_value", "f16_value", "n65536_value",
+              "rank_ms_per_step", "rho025_value", "rho005_value")
+
+
+def fit_line(line, budget=COMPACT_LINE_BUDGET):
+    """Bounds the stdout line: drops the lowest-priority secondary scalars, then shortens the free-text fields, until it fits.
+    The contract's fields, `roofline`, `cpu_baseline`, the fp32-grade `f16x3_value` and `dist` are never dropped."""
+    size = lambda: len(json.dumps(line))
+    for k in DROP_ORDER:
+        if size() <= budget:
+            return line
+        line.pop(k, None)
+    if size() > budget and "parity" in line:
+        line["parity"].pop("what", None)
+    if size() > budget and "cpu_baseline" in line:
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:48]
+    if size() > budget:
+        line["config"]["workload"] = line["config"]["workload"][:64]
     return line
 
 
@@ -596,6 +620,20 @@ def run_rank(args):
     rank, world, dev = D.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
+    if world > 1 and torch.cuda.is_available() and os.environ.get("MCNERF_SHARE_GPU") != "1":
+        # one GPU per rank over RCCL, or the scaling numbers mean something else: refuse to measure otherwise (utils/distributed_init.py:28-33
+        # binds LOCAL_RANK the same way).  Test rigs that share one GPU say so with MCNERF_SHARE_GPU=1 (+ MCNERF_DIST_BACKEND=gloo).
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        if torch.cuda.current_device() != local or dev.index != local:
+            raise SystemExit(f"bench.py: rank {rank} is on cuda:{torch.cuda.current_device()}, LOCAL_RANK is {local}")
+        if dist.get_backend() != "nccl":
+            raise SystemExit(f"bench.py: backend {dist.get_backend()!r} with one GPU per rank: the multi-GPU line is measured over RCCL (backend nccl)")
+    if args.also is None:          # defaults: every mode beside the headline at N = 1; at N > 1 the headline + the all-22-bit mode only,
+        args.also = "f16x3,f16,bf16,f32" if world == 1 else "f16x3"        # so that the line arrives well inside a driver's per-run timeout
+    if args.occupancy is None:
+        args.occupancy = "0.25,0.05" if world == 1 else ""
+    if args.extra is None:
+        args.extra = world == 1
     if args.selftest:                              # launcher / rendezvous check without kernels (runs on CPU over gloo)
         t = torch.ones(4, device=dev) * (rank + 1)
         if world > 1:
@@ -690,7 +728,7 @@ def run_rank(args):
                 out[k] = head[k]
         # the process group the numbers were taken on: `backend` "nccl" IS RCCL on ROCm (gloo only on the test rigs that share a GPU)
         out["dist"] = {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
-                       "rccl_ranks": (world if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0)),
+                       "rccl_ranks": (world if (world > 1 and dist.get_backend() == "nccl") else 0),      # (no process group at world 1: none exercised)
                        "one_gpu_per_rank": os.environ.get("MCNERF_SHARE_GPU") != "1"}
         if world == 1 and not args.no_cpu_baseline:
             # (the default mode beside the mode whose every operand is 22-bit, and the exact-fp32 mode: the same probe in each)
@@ -775,19 +813,21 @@ def main():
     ap.add_argument("--img", type=int, default=800, help="image side (BASELINE cfg 5: 1600)")
     ap.add_argument("--rig", default="ball", choices=["ball", "array", "halfball", "room"], help="camera rig of the synthetic scene")
     ap.add_argument("--coarse", default="4x128x2", help="coarse net depth x width x skip (config/config.yaml:76-78); 8x256x4 = SURVEY 8's second variant")
-    ap.add_argument("--occupancy", default="0.25,0.05", help="selected fractions of the fine grid measured beside the random-init line "
-                    "(by_occupancy; sigma-head bias shift, SURVEY 8(d)); empty = none")
+    ap.add_argument("--occupancy", default=None, help="selected fractions of the fine grid measured beside the random-init line "
+                    "(by_occupancy; sigma-head bias shift, SURVEY 8(d)); empty = none; default 0.25,0.05 at --gpus 1, none at --gpus > 1")
     ap.add_argument("--rho", type=float, default=None, help="pin the selected fraction of the HEADLINE run itself (profiling a low-occupancy step: "
                     "scripts/evidence.sh); the default line leaves the random-init weights as they are")
     ap.add_argument("--sigma-bias-shift", type=float, default=None, help="with --rho: apply this shift (from an earlier run's "
                     "`occupancy.sigma_bias_shift`) instead of calibrating")
-    ap.add_argument("--no-extra", dest="extra", action="store_false", help="skip extra_lines (8x256 coarse, N = 7000, 128x5, render)")
+    ap.add_argument("--no-extra", dest="extra", action="store_false", default=None, help="skip extra_lines (8x256 coarse, N = 7000, 128x5, render)")
+    ap.add_argument("--extra", dest="extra", action="store_true", help="extra_lines also at --gpus > 1 (default: only at --gpus 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f16x3h", choices=["f32", "f16x3", "f16x3h", "f16", "bf16"],
                     help="MFMA mode of the MLP kernels: split-f16 f16x3h (the headline: fp32-grade forward and dX chains, weight gradients from "
                          "the hi operand planes), f16x3 (every operand 22-bit) or exact f32 -- the 1e-4 parity modes; single-pass f16 / bf16 -- "
                          "16-bit operand modes with their own stated error")
-    ap.add_argument("--also", default="f16x3,f16,bf16,f32", help="other precision modes measured in the same run (by_precision)")
+    ap.add_argument("--also", default=None, help="other precision modes measured in the same run (by_precision); default f16x3,f16,bf16,f32 "
+                    "at --gpus 1, f16x3 at --gpus > 1")
     ap.add_argument("--mode", default="train", choices=["train", "render"])
     ap.add_argument("--full-json", default=os.path.join(ROOT, "bench_full.json"), help="where rank 0 writes the whole record (stdout gets the compact line)")
     ap.add_argument("--selftest", action="store_true", help="rendezvous / launcher check only (no kernels; works on CPU)")

@@ -171,7 +171,6 @@ class RenderTrainFn(torch.autograd.Function):
             # forward may already have overwritten it -- refuse instead of returning gradients of clobbered operands
             raise ops._lib.McnerfError("RenderTrainFn.backward ran twice on one forward (retain_graph): its saved-operand workspaces were "
                                   "returned to the pool by the first backward; run the forward again")
-        ctx.workspaces_given_back = True
         saved = ctx.saved_tensors
         rays_d, rays_o, jit, eps_c, barf_w, out_c, flat_c, packed_c = saved[:8]
         dev = rays_d.device
@@ -191,27 +190,40 @@ class RenderTrainFn(torch.autograd.Function):
         g_f = None
 
         def net_backward(model, flat, packed, zgrid, eps, out, d_rgb, save, grads, idx=None, count=None, max_rows=0):
-            if d_rgb is None:
-                return
+            """One net's composite backward, dX chain and weight gradients.  The saved-operand set goes back to the pool on EVERY way
+            out -- no gradient wanted, or an error (a range overflow raised by a kernel, out of memory in take_grad) --: a retried
+            step must find the pool as the forward left it, not one set short."""
             net = model.net
-            d_out, gmax = ops.composite_bwd(out, zgrid, jit, eps, d_rgb.contiguous(), st.white_back, want_gmax=True)
             pool = _pool(owner)
-            dy, dsh = pool.take_grad(net, save, st.precision)
-            ops.mlp_bwd(net, flat, packed, rays_o, rays_d, zgrid, jit, barf_w, out, d_out, save, dy, dsh,
-                        d_o, d_d, idx=idx, count=count, max_rows=max_rows, precision=st.precision, gmax=gmax)
-            rows = max_rows if idx is not None else N * zgrid.numel()
-            ops.mlp_dw(net, save, dy, dsh, grads, rows, count=count, precision=st.precision, gmax=gmax)
-            pool.give_grad(net, save, st.precision, (dy, dsh))
-            pool.give_save(net, save, st.precision)           # (everything that reads the set is enqueued: the next step may overwrite it)
+            try:
+                if d_rgb is None:
+                    return
+                d_out, gmax = ops.composite_bwd(out, zgrid, jit, eps, d_rgb.contiguous(), st.white_back, want_gmax=True)
+                dy, dsh = pool.take_grad(net, save, st.precision)
+                try:
+                    ops.mlp_bwd(net, flat, packed, rays_o, rays_d, zgrid, jit, barf_w, out, d_out, save, dy, dsh,
+                                d_o, d_d, idx=idx, count=count, max_rows=max_rows, precision=st.precision, gmax=gmax)
+                    rows = max_rows if idx is not None else N * zgrid.numel()
+                    ops.mlp_dw(net, save, dy, dsh, grads, rows, count=count, precision=st.precision, gmax=gmax)
+                finally:
+                    pool.give_grad(net, save, st.precision, (dy, dsh))
+            finally:
+                pool.give_save(net, save, st.precision)       # (everything that reads the set is enqueued: the next step may overwrite it)
 
+        # from here on the saved-operand sets leave this context, whatever happens: a second backward on a retained graph is refused
+        save_c, save_f = ctx.save_c, (None if ctx.only_coarse else ctx.save_f)
+        ctx.save_c = ctx.save_f = None
+        ctx.workspaces_given_back = True
         if not ctx.only_coarse:
             eps_f, out_f, flat_f, packed_f, idx, count = saved[8:]
             g_f = arena[n_c:n_c + n_f] if arena is not None else torch.zeros_like(flat_f)
-            net_backward(model_f, flat_f, packed_f, owner.z_vals_f, eps_f, out_f, d_rgb_f, ctx.save_f, g_f,
-                         idx=idx, count=count, max_rows=ctx.max_rows)
-            ctx.save_f = None
-        net_backward(model_c, flat_c, packed_c, owner.z_vals_c, eps_c, out_c, d_rgb_c, ctx.save_c, g_c)
-        ctx.save_c = None
+            try:
+                net_backward(model_f, flat_f, packed_f, owner.z_vals_f, eps_f, out_f, d_rgb_f, save_f, g_f,
+                             idx=idx, count=count, max_rows=ctx.max_rows)
+            except BaseException:
+                _pool(owner).give_save(model_c.net, save_c, st.precision)      # (the coarse net's set never reaches its own backward)
+                raise
+        net_backward(model_c, flat_c, packed_c, owner.z_vals_c, eps_c, out_c, d_rgb_c, save_c, g_c)
         grads_c = model_c.grad_views(g_c)
         grads_f = model_f.grad_views(g_f) if g_f is not None else [None] * len(model_f.ordered_parameters())
         owner.last_flat_grads = (g_c, g_f)

@@ -14,14 +14,17 @@ from mc_nerf_amd.model import NeRF_Model, MC_NeRF_Loss
 
 # gates per mode: (colours, parameter gradients, ray gradients; gradients relative to max(1, |g|max)).  f32 / f16x3 carry the 1e-4 bar
 # everywhere (a gradient that misses it is re-gated at 8 x the reference arithmetic's own reorder noise on that case, measured);
-# the 16-bit operand modes: parameter gradients at TWICE the operand type's unit roundoff (f16 2 x 4.9e-4, bf16 2 x 3.9e-3) of the
-# tensor's largest entry -- a weight gradient is a product of two rounded operands (dY and X), and a handful of samples does not
-# average that down: round 5's seed 12 drew a 4-ray, 63-sample case (2-layer fine net) that measures 5.8e-4 in f16; the 2 440
-# cases of seeds 1, 7, 8, 9, 11, 12 otherwise stay below one roundoff --, colours and ray gradients at ~4 x the worst of a 240-case sweep (seed 1: f16 1.5e-5 / 5.1e-5 / 3.7e-3, bf16 1.3e-4 / 1.5e-4 /
+# the 16-bit operand modes: parameter gradients at the operand type's unit roundoff (f16 4.9e-4, bf16 3.9e-3) of the tensor's largest
+# entry; colours and ray gradients at ~4 x the worst of a 240-case sweep (seed 1: f16 1.5e-5 / 5.1e-5 / 3.7e-3, bf16 1.3e-4 / 1.5e-4 /
 # 3.6e-3; f32 3.6e-7 / 7.3e-6 / 2.9e-5, f16x3 3.0e-7 / 2.0e-7 / 7.5e-6)
 # (ray gradients of the split-f16 chains: 3e-4 -- the gradient of the encoded channels passes the 2^9 frequency band, where 22-bit
 #  operands are 4 x the fp32 kernels' own rounding: 2 of 386 f16x3h cases of seed 7 measure 1.1e-4 / 1.5e-4, f32's worst is 5.9e-5)
-GATES = {"f32": (1e-4, 1e-4, 1e-4), "f16x3": (1e-4, 1e-4, 3e-4), "f16x3h": (1e-4, 1e-4, 3e-4), "f16": (1e-4, 9.8e-4, 1.5e-2), "bf16": (6e-4, 7.8e-3, 1.5e-2)}
+GATES = {"f32": (1e-4, 1e-4, 1e-4), "f16x3": (1e-4, 1e-4, 3e-4), "f16x3h": (1e-4, 1e-4, 3e-4), "f16": (1e-4, 4.9e-4, 1.5e-2), "bf16": (6e-4, 3.9e-3, 1.5e-2)}
+# A weight gradient is a sum over the evaluated samples of products of two rounded operands (dY and X): a handful of samples does not
+# average the two roundoffs down.  Only THERE -- fewer than SMALL_K fine samples -- the f16 gate is two roundoffs (round 5's seed 12
+# drew a 4-ray, 63-sample case, 2-layer fine net, that measures 5.8e-4; the 2 440 cases of seeds 1, 7, 8, 9, 11, 12 otherwise stay
+# below one roundoff in f16, and bf16's worst anywhere is 2.8e-4 against its 3.9e-3: no case behind a wider bf16 gate).
+SMALL_K, SMALL_K_GRAD_FACTOR = 1000, {"f16": 2.0}
 
 
 def one_case(rng, dev, verbose=True, general=False, modes=("f32", "f16x3")):
@@ -100,6 +103,8 @@ def one_case(rng, dev, verbose=True, general=False, modes=("f32", "f16x3")):
     topo = f" c={coarse.depth}x{cw}/{list(coarse.skips)} f={fine.depth}x{fw}/{list(fine.skips)} deg={deg} F={n_freqs}" if general else f" c={coarse.depth}x{cw} f={fine.depth}x{fw}"
     desc = f"S={samples}x{scale}{topo} n={n} barf={barf} wb={cfg.white_back} {precision} r={step_r:.2f}{' CAP' if capped else ''}"
     tol_rgb, tol_g, tol_r = GATES[precision]
+    if k < SMALL_K:
+        tol_g *= SMALL_K_GRAD_FACTOR.get(precision, 1.0)
     note = ""
     if gerr >= tol_g or rerr >= tol_r:      # sums with cancellation: how far does the REFERENCE arithmetic move on this case when the hidden
         #                                     units are enumerated in another order (oracle.permute_hidden_units)?  8 x that is the floor of the gate

@@ -37,7 +37,7 @@ def _device_elf(obj, tmp_path):
 def test_m0_is_written_only_by_the_ring_asm(obj, tmp_path):
     elf = _device_elf(obj, str(tmp_path))
     dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", elf], check=True, capture_output=True, text=True).stdout
-    assert dis.count("v_mfma_f32_32x32x16_f16") > 1000
+    assert dis.count("v_mfma_f32_32x32x16_f16") + dis.count("v_mfma_f32_16x16x32_f16") > 1000
     bad = []
     for line in dis.splitlines():
         ins = line.split("//")[0].strip()

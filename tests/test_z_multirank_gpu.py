@@ -110,14 +110,22 @@ def test_bench_two_ranks_share_one_gpu(gpu_device, tmp_path, world):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     full = os.path.join(str(tmp_path), "bench_full.json")
+    # world 2: the pinned-occupancy lines asked for explicitly (the DDP invariant on them); world 8: the DRIVER's form, nothing but --gpus /
+    # --steps / --warmup decided here -- at N > 1 bench.py then measures the headline mode + f16x3 only (no by_occupancy, no extra_lines)
+    extra = ["--also=", "--occupancy=0.25,0.05"] if world == 2 else []
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--rays", "2048", "--steps", "6", "--warmup", "2",
-                        "--also=", "--no-cpu-baseline", "--full-json", full], capture_output=True, text=True, timeout=400, env=env)
+                        "--no-cpu-baseline", "--full-json", full] + extra, capture_output=True, text=True, timeout=400, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     assert len(line) < 2048, len(line)                      # the stdout line the driver keeps is the compact one ...
     c = json.loads(line)
     assert c["n_gpus"] == world and c["dist"] == {"world_size": world, "backend": "gloo", "rccl_ranks": 0, "one_gpu_per_rank": False}
-    assert c["params_identical_across_ranks"] is True and c["asymmetric_grad_steps"] == 0 and c["rho005_value"] > 0
+    assert c["params_identical_across_ranks"] is True and c["asymmetric_grad_steps"] == 0
+    assert len(c["rank_ms_per_step"]) == world and c["allreduce_ms"] > 0 and c["roofline"]["frac"] > 0
+    if world == 2:
+        assert c["rho005_value"] > 0
+    else:
+        assert "rho005_value" not in c and c["f16x3_value"] > 0
     j = json.load(open(full))                               # ... and the whole record is the file it names
     assert c["full_record"] == "bench_full.json" and abs(j["value"] - c["value"]) < 1e-5 * j["value"]
     assert j["n_gpus"] == world and j["steps"] == 6 and j["scaling"] == "weak"
@@ -134,7 +142,7 @@ def test_bench_two_ranks_share_one_gpu(gpu_device, tmp_path, world):
 def test_bench_under_torchrun_with_one_rank_is_the_plain_line(gpu_device, tmp_path):
     """The driver's N = 1 forms: `python bench.py` and `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` must be
     the SAME path (no process group, no collective, no camera sharding) and report themselves so: n_gpus 1, dist.world_size 1,
-    rccl_ranks 1, parallelism dp1 -- and agree on the step time to the run-to-run spread of a 2048-ray step."""
+    rccl_ranks 0 (no communicator exists), parallelism dp1 -- and agree on the step time to the run-to-run spread of a 2048-ray step."""
     import json
     args = ["--gpus", "1", "--rays", "2048", "--steps", "20", "--warmup", "5", "--also=", "--occupancy=", "--no-extra", "--no-cpu-baseline"]
     recs = []
@@ -145,7 +153,7 @@ def test_bench_under_torchrun_with_one_rank_is_the_plain_line(gpu_device, tmp_pa
                            timeout=400, env=_clean_env())
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         c = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        assert c["n_gpus"] == 1 and c["dist"]["world_size"] == 1 and c["dist"]["rccl_ranks"] == 1 and c["config"]["parallelism"] == "dp1"
+        assert c["n_gpus"] == 1 and c["dist"]["world_size"] == 1 and c["dist"]["rccl_ranks"] == 0 and c["config"]["parallelism"] == "dp1"
         assert "allreduce_ms" not in c and c["valid"] is True
         recs.append(c)
     a, b = recs[0]["ms_per_step"], recs[1]["ms_per_step"]
