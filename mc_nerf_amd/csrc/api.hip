@@ -4,11 +4,7 @@
 #include "mcnerf_kernels.h"
 #include "mcnerf_16.h"
 #include "mcnerf_x3.h"
-#ifdef ABL_ALIAS     // (ablation build only: every workspace slot aliases slot 0 = same bytes moved, 1/10 of the footprint)
-#define MCN_ACT_STRIDE(capacity, width) ((size_t)0)
-#else
 #define MCN_ACT_STRIDE(capacity, width) ((size_t)(capacity) * (width))
-#endif
 #include <stdio.h>
 #include <string.h>
 

@@ -22,13 +22,9 @@
 #pragma once
 #include "mcnerf_common.h"
 
-#ifndef MCN16_SLAB
 #define MCN16_SLAB 16                 // fragments (1 KiB each) per ring slab (a multiple of 8: every wave issues SLAB / 8 pieces)
-#endif
 #define MCN16_RING (128 / MCN16_SLAB) // slabs in the LDS ring (128 KiB; a power of two)
-#ifndef MCN16_AHEAD
 #define MCN16_AHEAD (MCN16_RING - 2)  // slabs in flight ahead of the one being consumed (early sync: RING >= AHEAD + 2)
-#endif
 #define MCN16_PPW (MCN16_SLAB / 8)    // LDS-DMA pieces per wave and slab
 #define MCN16_WAVES 8
 #define MCN16_ROWS (32 * MCN16_WAVES) // rows per workgroup pass
@@ -161,9 +157,7 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 // max|d_out| (a device word written by composite_bwd) near 2^4.  The exponent is clamped so that a tiny but non-zero
 // maximum (below ~2^-96) cannot overflow the scale to +inf (1 / SG would be 0 and every dY inf / NaN); the backward and
 // the weight-gradient kernel MUST agree on SG, so both call this.
-#ifndef MCN16_SG_LOG2
 #define MCN16_SG_LOG2 4.f             // max|d_out| * SG lands in (2^(SG_LOG2 - 1), 2^SG_LOG2]
-#endif
 __device__ __forceinline__ float mcn16_grad_scale(float gmax) {
     return (gmax > 0.f && gmax < 3e38f) ? exp2f(fminf(MCN16_SG_LOG2 - ceilf(log2f(gmax)), 100.f)) : 1.f;
 }
@@ -223,19 +217,10 @@ __device__ __forceinline__ unsigned mcn16_pkmul(unsigned a, unsigned b) {
 }
 
 // workspace store of one fragment / mask vector (non-temporal: written once, read by a later kernel; keeps the packed
-// weights in L2).  (ABL16_* = timing-only ablation builds)
+// weights in L2).
 template <class V>
 __device__ __forceinline__ void mcn16_ws_store(const V& v, V* p) {
-#if defined(ABL16_PLAINSTORE)
-    *p = v;
-#elif defined(ABL16_SINKSTORE)      // (timing only: the value is computed, the store is not issued)
-    asm volatile("" ::"v"(v), "v"(p));
-#elif defined(ABL16_STORE_POLICY)   // (experiment: another cache policy on the workspace stores, e.g. -DABL16_STORE_POLICY='"sc0 sc1 nt"')
-    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off " ABL16_STORE_POLICY ::"v"(p), "v"(v) : "memory");
-    else __builtin_nontemporal_store(v, p);
-#else
     __builtin_nontemporal_store(v, p);
-#endif
 }
 
 // ---- the shared weight ring -------------------------------------------------------------------------------------
@@ -245,9 +230,7 @@ __device__ __forceinline__ void mcn16_ws_store(const V& v, V* p) {
 // A slab is synchronised EARLY, MCN16_PF fragments before the previous slab ends, so that the A-fragment prefetch
 // (MCN16_PF fragments ahead of the MFMAs) runs straight across slab boundaries: with RING = 8 and AHEAD <= 6 the slot
 // refilled at that point belongs to a slab every wave has already left.
-#ifndef MCN16_PF
 #define MCN16_PF 2      // (measured 1 / 2 / 3 / 4 / 6 / 8: the backward, which is short of registers, is 2 % faster at 1-2 than at 4; the forwards do not care)
-#endif
 struct Mcn16Ring {
     const char* src;          // packed stream + this lane's byte offset inside a slab (piece PPW * wave, lane * 16)
     unsigned lds_piece;       // LDS byte offset of this wave's first piece inside a slab (wave-uniform)
@@ -262,9 +245,6 @@ struct Mcn16Ring {
     const char* ubase;        // packed stream + this wave's first piece inside a slab (wave-uniform)
     unsigned voff;            // lane * 16
     const char* piece_base;   // (spread refill) wave-uniform source address of piece 0 of the slab being refilled
-#ifdef ABL16_NORING
-    bool first_fill;
-#endif
 };
 typedef __attribute__((address_space(3))) void* mcn16_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* mcn16_gbl_ptr_t;
@@ -300,30 +280,15 @@ __device__ __forceinline__ void mcn16_dma4(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void mcn16_ring_issue(Mcn16Ring& r, char* ring_lds) {
     const char* s = r.src + (size_t)r.src_slab * (MCN16_SLAB * 1024);
     const unsigned d = r.lds_base + r.issue_slot * (MCN16_SLAB * 1024) + r.lds_piece;
-#ifndef ABL16_NORING            // (timing experiment only: the ring is filled once and never refilled)
 #pragma unroll
     for (int i = 0; i < MCN16_PPW; ++i) mcn16_dma16(s + i * 1024, d + i * 1024);
-#else
-    if (r.first_fill) {
-#pragma unroll
-        for (int i = 0; i < MCN16_PPW; ++i) mcn16_dma16(s + i * 1024, d + i * 1024);
-    }
-#endif
     r.src_slab = (r.src_slab + 1 == r.n_slabs) ? 0 : r.src_slab + 1;
     r.issue_slot = (r.issue_slot + 1) & (MCN16_RING - 1);
 }
 // Synchronise the next slab: wait for this wave's pieces of it, rendezvous (every wave's pieces have landed), refill
 // the ring AHEAD slabs further on.  r.next_off = the slab's LDS byte offset.
 __device__ __forceinline__ void mcn16_ring_sync(Mcn16Ring& r, char* ring_lds) {
-#if defined(ABL16_NOBARRIER)   // (timing experiments only: NOT safe)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MCN16_PPW * (MCN16_AHEAD - 1)) : "memory");
-#elif defined(ABL16_NOSYNC)
-    asm volatile("" ::: "memory");
-#elif defined(MCN16_EXP_VMCNT)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MCN16_EXP_VMCNT) : "memory");
-#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MCN16_PPW * (MCN16_AHEAD - 1)) : "memory");
-#endif
     r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
     r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
     mcn16_ring_issue(r, ring_lds);
@@ -333,17 +298,9 @@ __device__ __forceinline__ void mcn16_ring_start(Mcn16Ring& r, char* ring_lds, c
     r.lds_piece = (MCN16_PPW * wave) * 1024;
     r.lds_base = (unsigned)reinterpret_cast<size_t>((mcn16_lds_ptr_t)ring_lds);
     r.src_slab = 0; r.n_slabs = n_slabs; r.issue_slot = 0; r.sync_slot = 0; r.next_off = 0;
-#ifdef ABL16_NORING
-    r.first_fill = true;
-#endif
 #pragma unroll
     for (int i = 0; i < MCN16_AHEAD; ++i) mcn16_ring_issue(r, ring_lds);
     mcn16_ring_sync(r, ring_lds);
-#ifdef ABL16_NORING
-    mcn16_ring_issue(r, ring_lds); mcn16_ring_issue(r, ring_lds);
-    r.issue_slot = (r.issue_slot + MCN16_RING - 2) & (MCN16_RING - 1);
-    r.first_fill = false;
-#endif
 }
 
 // One output tile's MFMA chain position inside a layer of F fragments: fragment f is read from the slab being consumed

@@ -18,20 +18,14 @@
 #pragma once
 #include "mcnerf_16.h"
 
-#ifndef MCNX3_SW
 #define MCNX3_SW 256.0f
-#endif
 #define MCNX3_SX 8.0f
 #define MCNX3_SLABF 8                  // logical fragments (hi + lo piece) per ring slab
-#ifndef MCNX3_PF
 #define MCNX3_PF 2                     // A fragments (pairs) read this many k-steps ahead of their MFMAs
-#endif
 
 // waves per workgroup by net width (the wave count decides rows per pass and ring pieces per wave): nets at least
 // MCNX3_WIDE_MIN wide run one wave per SIMD with 512 registers per lane
-#ifndef MCNX3_WIDE_MIN
 #define MCNX3_WIDE_MIN 128
-#endif
 static inline constexpr int mcnx3_waves(int width) { return width >= MCNX3_WIDE_MIN ? 4 : 8; }
 
 static inline int mcnx3_pad(int frags) { return (frags + MCNX3_SLABF - 1) / MCNX3_SLABF * MCNX3_SLABF; }
@@ -90,18 +84,7 @@ __device__ __forceinline__ float mcnx3_relu(float x) {       // integer max: no 
     return __builtin_bit_cast(float, i > 0 ? i : 0);
 }
 __device__ __forceinline__ f32x16 mcnx3_mfma(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
-#ifdef ABLX3_MFMA16     // (timing-only, results INVALID: the same MACs and pipe time as TWO v_mfma_f32_16x16x32_f16 on two quarters of the
-    //                     accumulator -- what the other MFMA shape would cost / save inside the real instruction stream: DESIGN.md 3.6)
-    typedef float f32x4m __attribute__((ext_vector_type(4)));
-    f32x4m c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c1, 0, 0, 0);
-    f32x16 r = c;
-    r[0] = c0[0]; r[1] = c0[1]; r[2] = c0[2]; r[3] = c0[3]; r[4] = c1[0]; r[5] = c1[1]; r[6] = c1[2]; r[7] = c1[3];
-    return r;
-#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-#endif
 }
 // acc += (ah + al) (bh + bl) without the lo * lo term; smallest terms first
 __device__ __forceinline__ void mcnx3_mfma3(f32x16& acc, const u32x4_t& ah, const u32x4_t& al, const u32x4_t& bh, const u32x4_t& bl) {
@@ -128,11 +111,7 @@ __device__ __forceinline__ void mcnx3_ring_issue(Mcn16Ring& r) {
 }
 template <int PPW>
 __device__ __forceinline__ void mcnx3_ring_sync(Mcn16Ring& r) {
-#ifdef MCNX3_EXP_VMCNT          // (timing experiment only, NOT safe: another wait count)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(MCNX3_EXP_VMCNT) : "memory");
-#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW * (MCN16_AHEAD - 1)) : "memory");
-#endif
     r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
     r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
     mcnx3_ring_issue<PPW>(r);
@@ -167,9 +146,7 @@ __device__ __forceinline__ void mcnx3_before_mfma(Mcn16Ring& r, Mcn16Cursor& c, 
 // slab of 768.  So the synchronisation (counted wait + barrier) stays where it was and the refill's pieces follow ONE PER
 // SECOND MFMA GAP: piece i of the slab synchronised in front of fragment s goes out in gap 3 s + 1 + 2 i of the layer (gap =
 // 3 f + g in front of MFMA g of fragment f), the pieces a layer's last gaps cannot take at its end (mcnx3_layer_end).
-#ifndef MCNX3_DMA_STEP
 #define MCNX3_DMA_STEP 2
-#endif
 // The refill's addresses are set up ONCE per slab at the synchronisation point -- the wave-uniform source address in a scalar
 // register pair, the LDS destination in M0 (nothing else in these kernels uses M0; the other LDS-DMA helpers save and restore it) --
 // and every piece is then a single instruction: the instruction's immediate offset advances both the global and the LDS address,
@@ -177,9 +154,6 @@ __device__ __forceinline__ void mcnx3_before_mfma(Mcn16Ring& r, Mcn16Cursor& c, 
 // 512-register saving forward spilled: reloaded from scratch at every slab of the sigma head, each reload a full vmcnt(0) drain.)
 template <int PPW>
 __device__ __forceinline__ void mcnx3_ring_piece(Mcn16Ring& r, int i) {
-#ifdef ABLX3_NODMA            // (timing-only: the ring is never refilled)
-    return;
-#endif
     switch (i) {              // (immediate offsets)
         case 0: asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(r.voff), "s"(r.piece_base) : "memory"); break;
         case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(r.voff), "s"(r.piece_base) : "memory"); break;
@@ -192,9 +166,7 @@ __device__ __forceinline__ void mcnx3_before_mfma_spread(Mcn16Ring& r, Mcn16Curs
     static_assert(PPW <= 4, "immediate offsets of the refill pieces");
     if ((f & (MCNX3_SLABF - 1)) == 0) c.cur = r.next_off;
     if (f == mcnx3_sync_at<F>(f / MCNX3_SLABF)) {
-#ifndef ABLX3_NOSYNC          // (timing-only: no wait, no barrier at the slab boundaries)
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPW * (MCN16_AHEAD - 1)) : "memory");
-#endif
         r.next_off = r.sync_slot * (MCN16_SLAB * 1024);
         r.sync_slot = (r.sync_slot + 1) & (MCN16_RING - 1);
         r.piece_base = r.ubase + (size_t)r.src_slab * (MCN16_SLAB * 1024);
@@ -229,97 +201,6 @@ __device__ __forceinline__ unsigned mcnx3_frag_off(const Mcn16Ring& r, const Mcn
     return (next ? r.next_off : c.cur) + (f & (MCNX3_SLABF - 1)) * 2048;
 }
 
-#endif   // __HIPCC__
-// ---- the 16 x 16 x 32 form of the chains ("two groups of 16 samples per wave") ---------------------------------------------
-// v_mfma_f32_16x16x32_f16 draws less per FLOP than the 32 x 32 x 16 shape (scripts/probe/mfma_shape.hip: 1.14 x the FLOP/s under the
-// chip's power limit, which is what bounds these kernels: DESIGN.md 3.6).  A wave still carries 32 samples, as TWO groups gi = 0, 1 of 16:
-// lane = 16 rg + n holds sample 16 gi + n of the wave's tile in row group rg = 0 .. 3.  An A piece (16 output rows x 32 contraction
-// positions, 1 KiB hi + 1 KiB lo: the same 2 KiB logical fragment, so ring, slabs and packed sizes do not change) feeds both groups:
-// the LDS bytes per MAC are those of the 32 x 32 form.
-//   * The 16 x 16 accumulator of output tile t2 holds, in lane (n, rg), rows 4 rg + i (i = 0 .. 3).  Which CHANNEL a row is, is a
-//     free choice of the weight packing; here row r of tile t2 = 2 so + u is channel
-//         row16(t2, r) = 32 so + 16 (r >> 3) + 8 u + 4 ((r >> 2) & 1) + (r & 3),
-//     i.e. tile 2 so computes channels 32 so + {0..7, 16..23} and tile 2 so + 1 the others.
-//   * With that choice the four words a lane packs from tiles 2 so, 2 so + 1 (its B fragment of k-step-of-32 so of the next layer)
-//     are EXACTLY the 16-byte chunk (k-step-of-16 s = 2 so + (rg >> 1), lane half h = rg & 1, sample m = 16 gi + n) of the 32-row
-//     fragment format of mcnerf_16.h, element order included: contraction position (so, rg, j) <-> channel
-//     mcn16_chan(2 so + (rg >> 1), rg & 1, j).  The saved planes, the ReLU bit words and the saved sh.2 tile therefore keep their
-//     formats without a shuffle (a fragment store is four 256-byte runs), and the weight-gradient kernels do not change.
-__host__ __device__ __forceinline__ constexpr int mcnx3_row16(int t2, int r) {
-    return 32 * (t2 >> 1) + 16 * (r >> 3) + 8 * (t2 & 1) + 4 * ((r >> 2) & 1) + (r & 3);
-}
-__host__ __device__ __forceinline__ constexpr int mcnx3_chan32(int s2, int rg, int j) { return mcn16_chan(2 * s2 + (rg >> 1), rg & 1, j); }
-// which chains consume their stream in that form (the packing kernel follows)
-#define MCNX3_FWD_GEO16 true
-#define MCNX3_BWD_GEO16 false
-#define MCNX3_ENCKS2 (MCN16_ENCKS / 2)   // k-steps of 32 of the 64 (63 + pad) encoded channels
-
-#ifdef __HIPCC__
-__device__ __forceinline__ f32x4 mcnx3_mfma16(const u32x4_t& a, const u32x4_t& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-}
-// (f16(a s), f16(b s)) packed, a in the low half: scale, conversion and packing in two v_fma_mix{lo,hi}_f16 (s a power of two: the
-// product is exact, the one rounding is the conversion's -- bit-identical to v_mul_f32 x 2 + v_cvt_pk_f16_f32)
-__device__ __forceinline__ unsigned mcnx3_pack_scaled(float a, float b, float s) {
-    unsigned w;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(w) : "v"(a), "s"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(w) : "v"(b), "s"(s));
-    return w;
-}
-// (f16(a s - hw.lo), f16(b s - hw.hi)) packed: the lo halves of the (hi, lo) split of (a s, b s) whose hi halves are hw.  a s is
-// exact, a s - hi is exact in fp32 (Sterbenz-like: hi is a s rounded to 11 bits), so this is the value mcnx3_residual + a pack give.
-__device__ __forceinline__ unsigned mcnx3_pack_residual(float a, float b, float s, unsigned hw) {
-    unsigned w;
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(w) : "v"(a), "s"(s), "v"(hw));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(w) : "v"(b), "s"(s), "v"(hw));
-    return w;
-}
-// mask bit ? b : a, as an opaque instruction.  A C++ select between two elements of a register-resident array (`c ? E[i + 4] : E[i]`)
-// is folded by hipcc into ONE load through a selected address, which turns the whole array into an indexed scratch array (and its
-// reads into vector-memory loads the compiler drains vmcnt for, once per pass).
-__device__ __forceinline__ float mcnx3_sel(float a, float b, unsigned long long mask) {
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
-    return r;
-}
-// lanes 32-63 of x <-> lanes 0-31 of y (v_permlane32_swap)
-__device__ __forceinline__ void mcnx3_swap32(unsigned& x, unsigned& y) {
-    const u32x2_t r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
-    x = r[0]; y = r[1];
-}
-// (floats: as inline asm -- hipcc 7.2 reads element 0 again when element 1 of the builtin's result vector is bit-cast to float, the
-//  miscompile of DESIGN.md 3.1's list; the instruction needs two wait states after a VALU write of its operands)
-__device__ __forceinline__ void mcnx3_swap32(float& x, float& y) {
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-}
-// The refill pieces of the 16 x 16 x 32 layer bodies: a fragment is six MFMA gaps (of 16 cycles) there; piece i of the slab synchronised in
-// front of fragment s goes out in gap 6 s + 2 + 3 i (the word items of the epilogues sit in gaps = 1 mod 3: mlp_x3_fwd.hip).
-template <int F, int PPW>
-__device__ __forceinline__ void mcnx3_gap_dma6(Mcn16Ring& r, int gap) {
-    // (the pieces of slab q lie in the gaps of fragments sync_at(q), sync_at(q) + 1: only the slab of this gap's fragment and the one
-    //  before it can match -- two candidates per gap keep the body small before the layer is unrolled)
-    const int q1 = (gap / 6) / MCNX3_SLABF;
-#pragma unroll
-    for (int dq = 0; dq < 2; ++dq) {
-        const int q = q1 - dq;
-        if (q < 0) continue;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i)
-            if (gap == 6 * mcnx3_sync_at<F>(q) + 2 + 3 * i) mcnx3_ring_piece<PPW>(r, i);
-    }
-}
-template <int F, int PPW>
-__device__ __forceinline__ void mcnx3_layer_end6(Mcn16Ring& r) {
-    constexpr int NQ = (F + MCNX3_SLABF - 1) / MCNX3_SLABF;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int i = 0; i < PPW; ++i)
-            if (6 * mcnx3_sync_at<F>(q) + 2 + 3 * i >= 6 * F) mcnx3_ring_piece<PPW>(r, i);
-}
-#endif
-
-#ifdef __HIPCC__
 // The 63 (+1 pad) encoded channels of one sample, each sin / cos within an fp32 rounding of the true value: one fp64 sin / cos per
 // axis, the octaves by the fp64 double-angle step (mcn_sincos_octaves: ~240 instructions per sample instead of 30 fp64 reductions +
 // fp32 polynomials = ~1200; round 4 had halved those 30 by splitting them over a sample's two lanes, at the price of 9 shuffles and of

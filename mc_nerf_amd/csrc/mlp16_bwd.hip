@@ -10,16 +10,6 @@
 // Replaces autograd through model/net_block.py:22-33, 67-78 and model/mc_nerf.py:602, 635, 690-691.
 #include "mcnerf_16.h"
 
-#ifdef MCN16_STAMPS     // (diagnostic build: in-kernel cycle stamps of the pass phases, read back by scripts/stamps16_bwd.py)
-__device__ unsigned long long g_mcn16_bstamps[64 * 16];
-extern "C" int mcnerf_debug_stamps16_bwd(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mcn16_bstamps), sizeof(g_mcn16_bstamps));
-}
-#define MCN16_BSTAMP(i) do { if (W == 256 && blockIdx.x < 64 && pass == (long long)blockIdx.x + 20ll * gridDim.x && lane == 0 && wave == 0) \
-        g_mcn16_bstamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define MCN16_BSTAMP(i) do { } while (0)
-#endif
 
 template <int W>
 struct Bwd16Smem {
@@ -190,11 +180,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
         }
     };
     auto buf_of = [&](int slot) { return (D + 1 - slot) % 3; };
-#ifdef ABL16_MASKL2
-    auto mask_lane_of = [&](long long pass_) { return a.mask_ws + ((size_t)((pass_ * MCN16_WAVES + wave) & 63) * 64 + lane) * MW; };
-#else
     auto mask_lane_of = [&](long long pass_) { return a.mask_ws + ((size_t)(pass_ * MCN16_WAVES + wave) * 64 + lane) * MW; };
-#endif
     unsigned mk0_s[MW], mk0_c[MW], mk0_t[MW];                  // (narrow nets) the first three slots of the coming pass
     {
         const unsigned* ml0 = mask_lane_of(blockIdx.x);
@@ -207,13 +193,8 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
         const long long tile = pass * MCN16_WAVES + wave;
         const long long g = tile * 32 + m;
         const bool valid = g < total;
-#ifdef ABL16_MASKL2      // (timing-only ablation: every pass reads the same few mask tiles = the reads hit in L2)
-        const unsigned* mask_lane = a.mask_ws + ((size_t)(tile & 63) * 64 + lane) * MW;
-#else
         const unsigned* mask_lane = a.mask_ws + ((size_t)tile * 64 + lane) * MW;
-#endif
         char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)tile * KS * 1024 + lane * 16;
-        MCN16_BSTAMP(0);
         // ---- per-sample prologue (lane-local): sigmoid and SH backward
         const int ray = cur.ray;
         unsigned mk_s[MW], mk_c[MW], mk_t[MW];
@@ -267,7 +248,6 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
             const long long gn = (pass_n * MCN16_WAVES + wave) * 32 + (lane >> 1);
             mcn16_dma4(reinterpret_cast<const int*>(a.idx) + 2 * (gn < total ? gn : total - 1) + (lane & 1), idx_lds);
         }
-        MCN16_BSTAMP(1);
         u32x4_t xa[KS], xb[KS];
         f32x16 denc[2];
         u32x4_t dencp[4];            // the skip layer's share of the encoded-input gradient, parked in 16 bit until layer 0
@@ -287,23 +267,19 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
             mcn16_ws_store(xa[s], reinterpret_cast<u32x4_t*>(dy_lane + (size_t)D * a.slot_bytes + s * 1024));
         }
         // ---- sigma.0^T (partial, 16 bit) ; sh.2^T -> dY of sh.0 ; sh.0^T + partial -> dY_{D-1}
-        MCN16_BSTAMP(2);
         if (D >= 2) mask_issue(mask_lane, D - 2, buf_of(D - 2));          // buffer 0 is free (the sigma path is done)
         unsigned mpend[MW];
         if (!MASK_DMA && D >= 2) mask_read(mask_lane, mpend, 0, D - 2);
         mcn16_bwd_seg<W, BF, KS, NT, 0>(ring, smem, lane, xa, xb, mk_s, denc, nullptr);
-        MCN16_BSTAMP(3);
         if (MASK_DMA) mask_read(mask_lane, mk_c, 1, D + 1);
         {
             u32x4_t dsh_in[KS];
             dsh_in[0] = dshf[0]; dsh_in[1] = dshf[1];
             mcn16_bwd_seg<W, BF, 2, NT, 1>(ring, smem, lane, dsh_in, xa, mk_c, denc, dy_lane + (size_t)(D + 1) * a.slot_bytes);
         }
-        MCN16_BSTAMP(4);
         if (D >= 3) mask_issue(mask_lane, D - 3, buf_of(D - 3));          // buffer 1 is free (sh.2^T is done)
         if (MASK_DMA) mask_read(mask_lane, mk_t, 2, D - 1);
         mcn16_bwd_seg<W, BF, KS, NT, 2>(ring, smem, lane, xa, xb, mk_t, denc, dy_lane + (size_t)(D - 1) * a.slot_bytes);
-        MCN16_BSTAMP(5);
         // ---- trunk, last layer to first: xb = dY_l
         for (int l = D - 1; l >= 1; --l) {
 #pragma unroll
@@ -323,7 +299,6 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
             }
             if (l == skip) mcn16_bwd_seg<W, BF, KS, 2, 0, 4>(ring, smem, lane, xa, dencp, mk_t, denc, nullptr);
             mcn16_bwd_seg<W, BF, KS, NT, 1>(ring, smem, lane, xa, xb, mk_t, denc, dy_lane + (size_t)(l - 1) * a.slot_bytes);
-            MCN16_BSTAMP(5 + D - l);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -353,7 +328,6 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
             shs1 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 2 * 1024 + 1024 + lane * 16);
         }
         mcn16_bwd_seg<W, BF, KS, 2, 3>(ring, smem, lane, xb, xa, mk_t, denc, nullptr);       // layer 0: encoded columns
-        MCN16_BSTAMP(13);
         // everything fetched for the next pass is waited for HERE, in front of the ray atomics (long landed: issued a whole
         // encoding backward earlier), so that the top of the next pass waits for nothing -- least of all for those atomics
         auto settle = [&]() {
@@ -450,7 +424,6 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
             }
         }
         if (!want_rays) settle();
-        MCN16_BSTAMP(14);
         cur = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -45,9 +45,7 @@ constexpr int dw16_pick(int N, int K, bool want_vn) {
     return want_vn ? bestVN : bestKT;
 }
 
-#ifndef DW16_STAGES
 #define DW16_STAGES 4
-#endif
 
 // tiles [t0, t1) of one segment: stream, accumulate, flush.  Leaves no LDS-DMA piece outstanding and every wave past the
 // barrier that follows the last LDS read, so the next segment's run may refill the ring at once.
@@ -200,13 +198,7 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int n = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-#if defined(DW16_ABL_NOEPI)       // (timing-only ablations of the accumulator flush)
-                    if (n >= sg.n_lo && n < sg.n_real && k_ok && acc[t][kt][e] == 12345.f) sg.dW[colk] = 0.f;
-#elif defined(DW16_ABL_WGSCOPE)
-                    if (n >= sg.n_lo && n < sg.n_real && k_ok) __hip_atomic_fetch_add(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + colk, acc[t][kt][e] * inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
                     if (n >= sg.n_lo && n < sg.n_real && k_ok) atomicAdd(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + colk, acc[t][kt][e] * inv);
-#endif
                 }
             }
         if (bias) {
@@ -232,14 +224,8 @@ __device__ __forceinline__ void dw16_run(const Dw16Seg& sg, const int t0, const 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int n = nbase + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
-#if defined(DW16_ABL_NOEPI)       // (timing-only ablations of the accumulator flush)
-                    if (n >= sg.n_lo && n < sg.n_real && k_ok && acc[t][kt][e] == 12345.f) sg.dW[colk] = 0.f;
-#elif defined(DW16_ABL_WGSCOPE)
-                    if (n >= sg.n_lo && n < sg.n_real && k_ok) __hip_atomic_fetch_add(sg.dW + (size_t)(n - sg.n_lo) * sg.ldw + colk, acc[t][kt][e] * inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
                     const int nr = sg.nmap ? mcn_sh_row(n - sg.n_lo, sg.nmap - 16) : n - sg.n_lo;      // (an SH degree below 2: its own row, or none)
                     if (n >= sg.n_lo && n < sg.n_real && k_ok && nr >= 0) atomicAdd(sg.dW + (size_t)nr * sg.ldw + colk, acc[t][kt][e] * inv);
-#endif
                 }
             }
         if (bias) {

@@ -98,9 +98,7 @@ __device__ __forceinline__ void mcn16_layer(Mcn16Ring& ring, char* smem, int lan
         if (i < 8) {
             const unsigned w = T::relu_pack(a[2 * i], a[2 * i + 1]);
             if (i < 4) o0[i] = w; else o1[i - 4] = w;
-#ifndef ABL16_NOMASK
             if (SAVE) mb = (i == 0) ? mcn16_nz(w) : ((mb << 1) | mcn16_nz(w));
-#endif
             if (EPI == 1) {
                 // (a float vector, not bit-cast integers: hipcc 7.2 folds fmaf((float)half, bit_cast<float>(u32x2[1]), acc) into a
                 //  v_fma_mix_f32 that reads element 0 again)
@@ -114,14 +112,8 @@ __device__ __forceinline__ void mcn16_layer(Mcn16Ring& ring, char* smem, int lan
                 if (SAVE) mw[t >> 1] |= mb << (8 * (t & 1));
             }
         } else if (SAVE) {
-#ifdef ABL16_NOSTORE      // (timing-only ablation: the stores are compiled but never executed)
-            if (reinterpret_cast<size_t>(mask_lane) == 1) {
-#endif
             if (i == 8) mcn16_ws_store(o0, reinterpret_cast<u32x4_t*>(save_lane + (2 * t) * 1024));
             else mcn16_ws_store(o1, reinterpret_cast<u32x4_t*>(save_lane + (2 * t + 1) * 1024));
-#ifdef ABL16_NOSTORE
-            }
-#endif
         }
     };
     cur.cur = ring.next_off;
@@ -135,15 +127,9 @@ __device__ __forceinline__ void mcn16_layer(Mcn16Ring& ring, char* smem, int lan
         for (int s = 0; s < KTOT; ++s) {
             const int f = t * KTOT + s;
             mcn16_before_mfma<F>(ring, smem, cur, f);
-#ifdef ABL16_HALFLDS      // (timing-only: every second A fragment is not read, its MFMA reuses the previous one -- what half the LDS reads would buy)
-            const u32x4_t a_now = af[(f & ~1) % MCN16_PF];
-            if (f + MCN16_PF < F && ((f + MCN16_PF) & 1) == 0)
-                af[f % MCN16_PF] = *reinterpret_cast<const u32x4_t*>(smem + mcn16_frag_off(ring, cur, f, f + MCN16_PF) + lane * 16);
-#else
             const u32x4_t a_now = af[f % MCN16_PF];
             if (f + MCN16_PF < F)
                 af[f % MCN16_PF] = *reinterpret_cast<const u32x4_t*>(smem + mcn16_frag_off(ring, cur, f, f + MCN16_PF) + lane * 16);
-#endif
             if (t > 0 && s >= START) {
 #pragma unroll
                 for (int i = (s - START) * SPS; i < (s - START + 1) * SPS; ++i)
@@ -163,16 +149,6 @@ __device__ __forceinline__ void mcn16_layer(Mcn16Ring& ring, char* smem, int lan
     }
 }
 
-#ifdef MCN16_STAMPS     // (diagnostic build: in-kernel cycle stamps of the pass phases, read back by scripts/stamps16.py)
-__device__ unsigned long long g_mcn16_fstamps[2 * 64 * 16];
-extern "C" int mcnerf_debug_stamps16_fwd(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mcn16_fstamps), sizeof(g_mcn16_fstamps));
-}
-#define MCN16_FSTAMP(i) do { if (W == 256 && blockIdx.x < 64 && pass == (long long)blockIdx.x + 20ll * gridDim.x && lane == 0 && wave == 0) \
-        g_mcn16_fstamps[((SAVE ? 64 : 0) + blockIdx.x) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define MCN16_FSTAMP(i) do { } while (0)
-#endif
 
 template <int W, bool SAVE, bool BF>
 __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16FwdArgs a) {
@@ -218,7 +194,6 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
         const long long g = tile * 32 + m;
         const bool valid = g < total;
         const long long gc = valid ? g : total - 1;
-        MCN16_FSTAMP(0);
         // ---- per-sample setup (lane-local; both lane halves of a sample compute the same values)
         int ray, j;
         if (a.idx) { const int2 rj = a.idx[gc]; ray = rj.x; j = rj.y; }
@@ -233,11 +208,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
         const int addr = ray * a.S + j;
         u32x4_t encf[MCN16_ENCKS];
         mcn16_encode<BF>(p, bw, h, encf);
-#ifdef ABL16_NOHBM      // (timing-only ablation: every workgroup writes the same few tiles = the stores issue but stay in cache)
-        const long long wtile = tile & 63;
-#else
         const long long wtile = tile;
-#endif
         char* act_lane = SAVE ? reinterpret_cast<char*>(a.act_ws) + (size_t)wtile * KS * 1024 + lane * 16 : nullptr;
         unsigned* mask_lane = SAVE ? a.mask_ws + ((size_t)wtile * 64 + lane) * MW : nullptr;
         if (SAVE) {
@@ -248,10 +219,8 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
 
         u32x4_t xa[KS], xb[KS];
         float dot = 0.f;
-        MCN16_FSTAMP(1);
         // ---- layer 0 (encoded input only), then the trunk; the skip layer takes [encoding, hidden]
         mcn16_layer<W, BF, SAVE, MCN16_ENCKS, 0, 0>(ring, smem, lane, encf, xa, xb, bias_h, nullptr, dot, act_lane, mask_lane);
-        MCN16_FSTAMP(2);
         for (int l = 1; l < D; ++l) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) xa[s] = xb[s];
@@ -259,18 +228,13 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
             unsigned* ml = SAVE ? mask_lane + (size_t)l * a.mask_slot_words : nullptr;
             if (l == skip) mcn16_layer<W, BF, SAVE, MCN16_ENCKS, KS, 0>(ring, smem, lane, encf, xa, xb, bias_h + l * W, nullptr, dot, sl, ml);
             else mcn16_layer<W, BF, SAVE, 0, KS, 0>(ring, smem, lane, encf, xa, xb, bias_h + l * W, nullptr, dot, sl, ml);
-            MCN16_FSTAMP(2 + l);
         }
         // ---- sigma head: hidden layer on the matrix pipe, the 1-wide output layer lane-local
         mcn16_layer<W, BF, SAVE, 0, KS, 1>(ring, smem, lane, encf, xb, xa, bias_h + D * W, w2_h, dot,
                                            SAVE ? act_lane + (size_t)D * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)D * a.mask_slot_words : nullptr);
-        MCN16_FSTAMP(10);
         // ---- SH head: hidden layer (reads the same trunk output), then the 27 (32) coefficient rows
-#ifndef ABL16_NOSHHIDDEN   // (timing-only ablation: one 128-MFMA layer body less in the instruction stream)
         mcn16_layer<W, BF, SAVE, 0, KS, 0>(ring, smem, lane, encf, xb, xa, bias_h + (D + 1) * W, nullptr, dot,
                                            SAVE ? act_lane + (size_t)(D + 1) * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)(D + 1) * a.mask_slot_words : nullptr);
-#endif
-        MCN16_FSTAMP(11);
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -287,7 +251,6 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
                 acc = T::mfma(af, xa[s], acc);
             }
         }
-        MCN16_FSTAMP(12);
         if (SAVE) {          // the SH coefficients (bias included) for the backward's view-direction term: 2 fragments of 16 bit
             char* e = reinterpret_cast<char*>(a.sh_ws) + (size_t)tile * 2 * 1024 + lane * 16;
             u32x4_t s0, s1;
@@ -324,7 +287,6 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_fwd_kernel(Mcn16Fwd
             o[1 + c] = 1.0f / (1.0f + expf(-pc));
         }
         if (valid && h == 0) *reinterpret_cast<f32x4*>(a.out + (size_t)addr * 4) = o;
-        MCN16_FSTAMP(13);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ring pieces still in flight must land before the LDS is released
 }

@@ -18,9 +18,7 @@ struct DwSeg {
 };
 
 // cache policy of the operand stream (LDS-DMA aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1): the rows are read once
-#ifndef MCN_DW_AUX
 #define MCN_DW_AUX 2
-#endif
 #define DW_SLAB_ROWS 16
 template <int V> struct VecT;
 template <> struct VecT<1> { typedef float T; };

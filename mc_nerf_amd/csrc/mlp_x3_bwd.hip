@@ -11,9 +11,7 @@
 // Replaces autograd through model/net_block.py:22-33, 67-78 and model/mc_nerf.py:602, 635, 690-691.
 #include "mcnerf_x3.h"
 
-#ifndef MCNX3_BWD_PREF_MINW      // narrowest net whose per-sample inputs and ReLU bits arrive by LDS-DMA one pass ahead (a build knob for A/B timing)
 #define MCNX3_BWD_PREF_MINW 256
-#endif
 #include <cstdlib>
 
 template <int W>
@@ -48,13 +46,8 @@ __device__ __forceinline__ void mcnx3_bwd_seg(Mcn16Ring& ring, char* smem, int l
     constexpr int LASTA = EPI ? START + 14 / IPG : 0;             // gap of the last item that reads the accumulator (item 14)
     // (the four fragment stores of a tile one every SSTR gaps behind the word items where the tile has room, not back to back:
     //  mlp_x3_fwd.hip; the two-items-per-gap form of the forward measured 2 % slower here on the 128-wide net)
-#ifndef MCNX3_NO_SPREAD
     constexpr int SBASE = START + 16, SSTR = (G - SBASE) / 4 > 0 ? (G - SBASE) / 4 : 1;
     constexpr bool STAG = (MODE == 1 || MODE == 2) && IPG == 1 && (G - SBASE) / 4 >= 2;
-#else
-    constexpr int SBASE = 0, SSTR = 1;
-    constexpr bool STAG = false;
-#endif
     constexpr int NITG = STAG ? 16 : NIT;
     constexpr int INIT_G = (G - 8) > LASTA ? (G - 8) : LASTA;     // the next tile's accumulator (= the set just drained) is initialised from here,
     constexpr int INIT_N = (INIT_G + 3 <= G - 1) ? 4 : 1;         // a quarter per gap where there is room
@@ -260,11 +253,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         }
     };
     auto buf_of = [&](int slot) { return (D + 1 - slot) % 3; };
-#ifdef ABLX3_MASKL2      // (timing-only ablation: every pass reads the same few mask tiles = the reads hit in L2)
-    auto mask_lane_of = [&](long long pass_) { return a.mask_ws + ((size_t)((pass_ & 1) * WAVES + wave) * 64 + lane) * MW; };
-#else
     auto mask_lane_of = [&](long long pass_) { return a.mask_ws + ((size_t)(pass_ * WAVES + wave) * 64 + lane) * MW; };
-#endif
     unsigned mk0_s[MW], mk0_c[MW], mk0_t[MW];                  // (narrow nets) the first three slots of the coming pass
     {
         const unsigned* ml0 = mask_lane_of(blockIdx.x);
@@ -278,11 +267,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         const long long g = tile * 32 + m;
         const bool valid = g < total;
         const unsigned* mask_lane = mask_lane_of(pass);
-#ifdef ABLX3_STOREWIN    // (timing-only ablation: every pass writes the same few tiles = the stores issue but stay in cache)
-        char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)(tile & 3) * (PL * KS) * 1024 + lane * 16;
-#else
         char* dy_lane = reinterpret_cast<char*>(a.dy_ws) + (size_t)tile * (PL * KS) * 1024 + lane * 16;
-#endif
         // ---- per-sample prologue (lane-local): sigmoid and SH backward
         if (PREFB) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_TOP) : "memory");       // (the first pass: vmcnt(0) was waited for below the mask prefetch)
@@ -355,11 +340,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         if (PREFB && want_rays) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-#ifdef ABLX3_SHSL2       // (timing-only ablation: the saved sh.2 outputs from the same few tiles)
-                shs[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)(tile & 7) * 4096 + q * 1024 + lane * 16);
-#else
                 shs[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.sh_ws) + (size_t)tile * 4096 + q * 1024 + lane * 16);
-#endif
         }
         u32x4_t xah[KS], xal[KS], xbh[KS], xbl[KS];
         f32x16 denc[2];
@@ -570,9 +551,6 @@ static hipError_t launch_bwd_x3(const Mcn16BwdArgs& a, long long max_rows, hipSt
     long long passes = (max_rows + ROWS - 1) / ROWS;
     if (passes <= 0) return hipSuccess;
     int grid = (int)(passes < cus ? passes : cus);
-#ifdef MCNERF_EXPERIMENTS      // (scripts/experiments/overlap_probe.py: a grid cap read per launch; not in the product build)
-    if (const char* e = getenv("MCNERF_EXP_CHAIN_GRID")) { int g = atoi(e); if (g > 0 && g < grid) grid = g; }
-#endif
     void (*kern)(Mcn16BwdArgs) = a.bf16 == 3 ? mlp_x3_bwd_kernel<W, true> : mlp_x3_bwd_kernel<W, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SM::total);
     if (e != hipSuccess) return e;

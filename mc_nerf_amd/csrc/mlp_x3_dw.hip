@@ -335,9 +335,6 @@ static hipError_t dwx3_launch_job(const DwX3Job& job, const int* count, int rows
     const long long ntiles = (rows_cap + 31) / 32;
     long long grid = dwx3_num_cus();
     if (grid > ntiles * job.n) grid = ntiles * job.n;
-#ifdef MCNERF_EXPERIMENTS      // (scripts/experiments/overlap_probe.py: a grid cap read per launch; not in the product build)
-    if (const char* e = getenv("MCNERF_EXP_DW_GRID")) { long long g = atoll(e); if (g > 0 && g < grid) grid = g; }
-#endif
     // LDS: the largest stages x stage product over the shapes of this width
     constexpr int KS = W / 16;
     constexpr int p0 = 2 * (2 * KS), p1 = 2 * (KS + MCN16_ENCKS), p2 = 2 * (2 + KS), p3 = 2 * (2 * KS + MCN16_ENCKS);

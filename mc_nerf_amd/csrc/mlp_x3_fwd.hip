@@ -3,11 +3,6 @@
 // through the whole network in registers as (hi, lo) f16 fragment pairs, three MFMAs per k-step into one fp32
 // accumulator; the waves of a workgroup share the LDS ring that streams the packed (hi, lo) weight pieces.
 // Persistent: one workgroup per CU walks the passes.
-//
-// MFMA shape: v_mfma_f32_16x16x32_f16, the wave's 32 samples as two groups of 16 (mcnerf_x3.h, "the 16 x 16 x 32 form"): lane =
-// 16 rg + n holds sample 16 gi + n of group gi in row group rg.  The per-sample work (inputs, encoding, sigma / colour epilogue)
-// is done ONCE per sample pair of lanes, as before: lane L "owns" sample m = 16 (L >> 5) + (L & 15) (copy r1 = (L >> 4) & 1), and
-// what the other group's fragments need crosses the wave halves by v_permlane32_swap.
 // Replaces (fp32-grade arithmetic: 22-bit operands, fp32 accumulate / bias / ReLU / epilogues) SinCosEmbedding.forward
 // (model/net_block.py:20-35), CorseFine_NeRF.forward (model/net_block.py:67-78), eval_sh (model/net_utils.py:103-191)
 // and the gather / scatter of NeRF_Model.inference (model/mc_nerf.py:688-701).
@@ -16,137 +11,97 @@
 template <int W>
 struct FwdX3Smem {
     static constexpr int oBias = MCN16_RING * MCN16_SLAB * 1024;   // fp32 [MAXD + 2][W]: trunk, sigma.0, sh.0 biases x (SX SW)
-    static constexpr int oW2 = oBias + (MCN_MAXD + 2) * W * 4;     // sigma.2 weight row [W] / SW
+    static constexpr int oW2 = oBias + (MCN_MAXD + 2) * W * 4;     // sigma.2 weight row [W]
     static constexpr int oBc2 = oW2 + W * 4;                        // sh.2 bias [32] (27 + zero pad) x (SX SW)
     static constexpr int oIdx = oBc2 + 32 * 4;                      // per wave: the NEXT pass's (ray, sample) pairs [32][2] (LDS-DMA)
     static constexpr int oIn = oIdx + mcnx3_waves(W) * 256;         // per wave: the next pass's per-sample inputs, 8 x [64 lanes] dwords (LDS-DMA gathers)
     static constexpr int total = oIn + mcnx3_waves(W) * 8 * 256;
 };
 
-// float offset of the first of the four consecutive channels that rows 4 rg .. 4 rg + 3 of tile t2 are, less the lane's part
-// 16 (rg >> 1) + 4 (rg & 1) (mcnx3_row16)
-__host__ __device__ constexpr int mcnx3_tile_off(int t2) { return 32 * (t2 >> 1) + 8 * (t2 & 1); }
-// Placement of a tile's NIT epilogue items in the G MFMA gaps of the tile that follows: one item every STRIDE gaps from gap START
-// where the tile has that many gaps (START = 3, or as late as fits: the drained tile's last MFMAs have landed by then, no wait state
-// in front of the first ReLU item), IPG per gap from gap 1 otherwise.
-__host__ __device__ constexpr int mcnx3_item_stride(int G, int NIT) {
-    const int stride = G / NIT;
-    return (stride >= 1 && 1 + stride * (NIT - 1) <= G - 1) ? stride : 0;
-}
-__host__ __device__ constexpr int mcnx3_item_start(int G, int NIT) {
-    const int stride = mcnx3_item_stride(G, NIT);
-    if (stride == 0) return 1;
-    const int room = G - 1 - stride * (NIT - 1);           // the latest start that still fits
-    return room < 3 ? room : 3;
-}
-__host__ __device__ constexpr int mcnx3_items_per_gap(int G, int NIT) { return (NIT + (G - 1) - 1) / (G - 1); }
-
-// One layer: NT output tiles of 16 channels, each the chain of KENC encoded-input k-steps and KHID hidden-input k-steps (of 32
-// channels) over the (hi, lo) A pieces taken from the weight ring in stream order; per k-step and group three MFMAs (lo*hi, hi*lo,
-// hi*hi), the two groups alternating.
+// One layer: NT output tiles, each the chain of KENC encoded-input k-steps and KHID hidden-input k-steps over the (hi, lo)
+// A pieces taken from the weight ring in stream order, three MFMAs per k-step.
 //   EPI 0: out = split(relu(acc / SW)) as the next layer's fragments (saved with their ReLU bits when SAVE)
-//   EPI 1: the sigma head's hidden layer: additionally dot[gi] += sum_n relu(acc)[n] * (w2[n] / SW)
-// Software pipeline pinned with sched_barriers: A pieces are read MCNX3_PF k-steps ahead; the epilogue of tile t is cut into items of
-// TWO independent vector instructions -- the same step for the two groups' words, so that no item reads what its first instruction
-// wrote (v_fma_mix{lo,hi} are partial writes: a dependent neighbour costs a wait state) -- issued one item every second MFMA gap
-// of tile t + 1 (a gap hides two vector instructions beside a 16-cycle MFMA).  The ReLU items come first and copy: tile t's accumulator
-// set is free after four items and takes tile t + 2's (scaled) bias straight from LDS.  A lane's four words of tiles 2 so, 2 so + 1 are
-// one 16-byte chunk of the saved plane: stored two tiles later.
+//   EPI 1: the sigma head's hidden layer: additionally dot += sum_n relu(acc / SW)[n] * w2[n]
+// Software pipeline pinned with sched_barriers: A pieces are read MCNX3_PF k-steps ahead; the epilogue of tile t (16 work
+// items of <= 9 vector instructions + 4 stores) is issued one item per MFMA gap of tile t + 1, whose accumulator is the
+// other of two register sets and starts at the (scaled) bias.
 //   SV 0: nothing saved; 1: the (hi, lo) fragment planes + ReLU bits; 2: the hi plane only, in the 16-bit modes' workspace layout (dtype 3:
 //   the weight-gradient kernel of that mode is the single-pass f16 one on the hi planes)
 template <int W, int SV, int KENC, int KHID, int EPI, int PPW>
-__device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lane, float isw,
-                                            const u32x4_t (&ench)[2][MCNX3_ENCKS2], const u32x4_t (&encl)[2][MCNX3_ENCKS2],
-                                            const u32x4_t (&inh)[2][W / 32], const u32x4_t (&inl)[2][W / 32],
-                                            u32x4_t (&outh)[2][W / 32], u32x4_t (&outl)[2][W / 32], const float* bias_l,
-                                            const float* w2_l, float (&dot)[2], char* save_lane, unsigned* mask_lane, unsigned msh) {
+__device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lane,
+                                            const u32x4_t (&ench)[MCN16_ENCKS], const u32x4_t (&encl)[MCN16_ENCKS],
+                                            const u32x4_t (&inh)[W / 16], const u32x4_t (&inl)[W / 16],
+                                            u32x4_t (&outh)[W / 16], u32x4_t (&outl)[W / 16], const float* bias_h,
+                                            const float* w2_h, float& dot, char* save_lane, unsigned* mask_lane) {
     constexpr bool SAVE = SV != 0, HI = SV == 2;
-    constexpr int NT = W / 16, KS2 = W / 32, KS = W / 16, KTOT = KENC + KHID, F = NT * KTOT, MW = W >= 64 ? W / 64 : 1;
-    constexpr int G = 6 * KTOT;                                   // MFMA gaps per tile
-    // items of one tile's epilogue: 4 ReLU items (group x word), then per word p (both groups in every item):
-    //   hi.lo-half, hi.hi-half, lo.lo-half, lo.hi-half [, ReLU bit, bit word][, sigma dot x 2]
-    constexpr int PER_P = 4 + (SAVE ? 2 : 0) + (EPI == 1 ? 2 : 0), NIT = 4 + 2 * PER_P;
-    constexpr int STRIDE = mcnx3_item_stride(G, NIT), START = mcnx3_item_start(G, NIT), IPG = mcnx3_items_per_gap(G, NIT);
-    constexpr int RELU_DONE = STRIDE > 0 ? START + 3 * STRIDE : 1 + 3 / IPG;    // gap of the last item that reads the drained accumulators
-    constexpr int BG = (G - 6 > RELU_DONE + 1) ? G - 6 : RELU_DONE + 1;         // the next tile's accumulators (that set) take the bias here
-    constexpr int SG_H = G >= 18 ? 9 : G - 2, SG_L = G >= 18 ? 15 : G - 1;     // gaps of the fragment stores
-    static_assert(BG <= G - 1, "bias gap");
+    constexpr int NT = W / 32, KS = W / 16, KTOT = KENC + KHID, F = NT * KTOT, MW = W >= 64 ? W / 64 : 1;
+    constexpr int G = 3 * KTOT;                                   // MFMA gaps per tile
+    constexpr bool HAS2 = SAVE || EPI == 1;                       // a word has a second item (ReLU bit, sigma dot)
+    constexpr int IPW = HAS2 ? 3 : 2;                             // items per packed word
+    constexpr int NST = SAVE ? (HI ? 2 : 4) : 0;                  // fragment stores of a tile
+    constexpr int NIT = 8 * IPW + NST;                            // work items of one tile's epilogue (each <= 6 vector instructions)
+    // Placement of a tile's epilogue in the gaps of the next tile.  With fragment stores (SAVE) and room for it: the word items from
+    // gap 3 (the previous tile's last MFMA must have landed), IPG per gap, then the four stores one every SSTR gaps over the rest of
+    // the tile instead of back to back (same-box A/B, 3.28 M rows of the 256-wide net: saving forward 12.12 -> 11.72 ms, backward
+    // 11.46 -> 11.33 ms; a gap of its own per (store, wave) pair needs a scalar branch per store and costs + 15 %).  Otherwise all
+    // items in order, as many per gap as it takes.
+    constexpr int NWI = 8 * IPW;                                  // word items
+    constexpr int ROOM = G - 3 - 2 * NST;                         // gaps for the word items when every store gets two
+    constexpr int IPGA = ROOM > 0 ? (NWI + ROOM - 1) / ROOM : 99;
+    constexpr bool STAG = SAVE && IPGA <= 2;
+    constexpr int START = STAG ? 3 : (G >= NIT + 4 ? 3 : 0);      // first gap that carries an item
+    constexpr int IPG = STAG ? IPGA : (NIT + (G - START) - 1) / (G - START);    // items per gap
+    constexpr int NITG = STAG ? NWI : NIT;                        // items placed by the items-per-gap rule
+    constexpr int LASTG = START + (NITG + IPG - 1) / IPG - 1;     // gap of the last of them
+    constexpr int SBASE = LASTG + 1, SSTR = STAG ? (G - SBASE) / NST : 1;
+    constexpr int BIAS_G = (G - 6) > LASTG ? (G - 6) : LASTG;     // the next tile's accumulator (= the set just drained) is loaded here
     Mcn16Cursor cur;
-    unsigned mwd[2][MW], mb[2] = {0u, 0u}, macc[2] = {0u, 0u};
+    unsigned mw[MW];
 #pragma unroll
-    for (int i = 0; i < MW; ++i) { mwd[0][i] = 0u; mwd[1][i] = 0u; }
+    for (int i = 0; i < MW; ++i) mw[i] = 0u;
     u32x4_t afh[MCNX3_PF], afl[MCNX3_PF];
-    f32x4 acc[2][2];                              // [register set][group]
-    f32x4 w2q = {0.f, 0.f, 0.f, 0.f};
-    float rv[2][2][2];                            // [group][word][element]: relu(acc) of the tile being drained
-    unsigned hw[2] = {0u, 0u}, lw[2] = {0u, 0u}, nzb[2] = {0u, 0u};      // per group: the words in flight
+    f32x16 acc[2];
+    unsigned mb = 0u;
+    float v0 = 0.f, v1 = 0.f;
+    unsigned wkeep = 0u;                          // the hi word of the pair in flight between its two items (hipcc 7.2 reads
+                                                  // element 0 when an element of a u32x4 is bit-cast to f16x2: never re-read it from the vector)
+    auto bias_init = [&](f32x16& a, int t) {
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi)
+        for (int q = 0; q < 4; ++q) {            // accumulator starts at the bias: rows 32t + 8q + 4h + e
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + 32 * t + 8 * q);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) { rv[gi][p][0] = 0.f; rv[gi][p][1] = 0.f; }
-    // work item k of the epilogue of tile t (accumulators a[group])
-    auto item = [&](const f32x4 (&a)[2], int t, int k) {
-        const int so = t >> 1, u = t & 1;
-        if (k < 4) {
-            const int gi = k & 1, p = k >> 1;
-            rv[gi][p][0] = mcnx3_relu(a[gi][2 * p]);
-            rv[gi][p][1] = mcnx3_relu(a[gi][2 * p + 1]);
-            return;
+            for (int e = 0; e < 4; ++e) a[4 * q + e] = b[e];
         }
-        const int p = (k - 4) / PER_P, j = (k - 4) % PER_P;
-        if (j == 0) {
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi) asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hw[gi]) : "v"(rv[gi][p][0]), "s"(isw));
-        } else if (j == 1) {
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hw[gi]) : "v"(rv[gi][p][1]), "s"(isw));
-                outh[gi][so][2 * u + p] = hw[gi];
-            }
-        } else if (j == 2) {          // the lo halves of the (hi, lo) split: f16(r / SW - hi), r / SW and the difference exact in fp32
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi)
-                asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lw[gi]) : "v"(rv[gi][p][0]), "s"(isw), "v"(hw[gi]));
-        } else if (j == 3) {
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lw[gi]) : "v"(rv[gi][p][1]), "s"(isw), "v"(hw[gi]));
-                outl[gi][so][2 * u + p] = lw[gi];
-            }
-        } else if (SAVE && j == 4) {
-            nzb[0] = mcn16_nz(hw[0]);
-            nzb[1] = mcn16_nz(hw[1]);
-        } else if (SAVE && j == 5) {      // this lane's four bits of k-step-of-16 2 so + (rg >> 1): words 0 .. 3, the first one highest
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                mb[gi] = (u == 0 && p == 0) ? nzb[gi] : ((mb[gi] << 1) | nzb[gi]);
-                if (u == 1 && p == 1) {
-                    macc[gi] = (so & 1) ? (macc[gi] | (mb[gi] << 8)) : mb[gi];
-                    if ((so & 1) || so == KS2 - 1) mwd[gi][so >> 1] = macc[gi] << msh;
+    };
+    // work item i of the epilogue of tile t (accumulator a)
+    auto item = [&](const f32x16& a, int t, int i) {
+        if (i < 8 * IPW) {
+            const int p = i / IPW, ph = i % IPW;  // packed word p of the tile: registers 2p, 2p + 1
+            if (ph == 0) {
+                v0 = mcnx3_relu(a[2 * p] * (1.0f / MCNX3_SW));
+                v1 = mcnx3_relu(a[2 * p + 1] * (1.0f / MCNX3_SW));
+                const unsigned w = Mcn16T<false>::pack(v0, v1);
+                wkeep = w;
+                outh[2 * t + (p >> 2)][p & 3] = w;
+            } else if (ph == IPW - 1) {
+                outl[2 * t + (p >> 2)][p & 3] = Mcn16T<false>::pack(mcnx3_residual<0>(v0, wkeep), mcnx3_residual<1>(v1, wkeep));
+            } else {
+                if (SAVE) {
+                    mb = (p == 0) ? mcn16_nz(wkeep) : ((mb << 1) | mcn16_nz(wkeep));
+                    if (p == 7) mw[t >> 1] |= mb << (8 * (t & 1));
+                }
+                if (EPI == 1) {
+                    const f32x2_t ww = *reinterpret_cast<const f32x2_t*>(w2_h + 32 * t + 8 * (p >> 1) + 2 * (p & 1));
+                    dot = fmaf(v0, ww[0], dot);
+                    dot = fmaf(v1, ww[1], dot);
                 }
             }
-        } else {                          // EPI 1: the sigma output layer's dot, one element of the word per item
-            const int e = j - (PER_P - 2);
-            dot[0] = fmaf(rv[0][p][e], w2q[2 * p + e], dot[0]);
-            dot[1] = fmaf(rv[1][p][e], w2q[2 * p + e], dot[1]);
+        } else if (SAVE) {
+            const int k = i - 8 * IPW;           // 0, 1: hi plane k-steps 2t, 2t + 1; 2, 3: lo plane
+            const int s = 2 * t + (k & 1);
+            if (k < 2) mcn16_ws_store(outh[s], reinterpret_cast<u32x4_t*>(save_lane + s * 1024));
+            else mcn16_ws_store(outl[s], reinterpret_cast<u32x4_t*>(save_lane + (KS + s) * 1024));      // (items k = 2, 3 do not exist with HI)
         }
-    };
-    // the plane chunks of (group gi, k-step-of-32 so): complete once the items of tile 2 so + 1 are done
-    auto store_hi = [&](int gi, int so) {
-        mcn16_ws_store(outh[gi][so], reinterpret_cast<u32x4_t*>(save_lane + so * 2048 + gi * 256));
-    };
-    auto store_lo = [&](int gi, int so) {
-        mcn16_ws_store(outl[gi][so], reinterpret_cast<u32x4_t*>(save_lane + KS * 1024 + so * 2048 + gi * 256));
-    };
-    // (two reads of the same quad, through two pointers the compiler cannot tell equal: each group's accumulator is loaded in place and
-    //  every MFMA of the tile is acc = A B + acc on one register quad -- with one shared read the first MFMAs write other registers than
-    //  they read and the register rotation costs wait states in front of whatever re-uses them)
-    int off1 = 0;
-    asm volatile("" : "+v"(off1));                  // (an opaque zero OFFSET: a laundered pointer would lose its LDS address space)
-    const float* bias_l1 = bias_l + off1;
-    auto bias_init = [&](f32x4 (&a)[2], int t) {
-        a[0] = *reinterpret_cast<const f32x4*>(bias_l + mcnx3_tile_off(t));
-        a[1] = *reinterpret_cast<const f32x4*>(bias_l1 + mcnx3_tile_off(t));
     };
     cur.cur = ring.next_off;
 #pragma unroll
@@ -168,59 +123,35 @@ __device__ __forceinline__ void mcnx3_layer(Mcn16Ring& ring, char* smem, int lan
                 afh[f % MCNX3_PF] = *reinterpret_cast<const u32x4_t*>(smem + o);
                 afl[f % MCNX3_PF] = *reinterpret_cast<const u32x4_t*>(smem + o + 1024);
             }
+            const u32x4_t b_h = s < KENC ? ench[s < KENC ? s : 0] : inh[s >= KENC ? s - KENC : 0];
+            const u32x4_t b_l = s < KENC ? encl[s < KENC ? s : 0] : inl[s >= KENC ? s - KENC : 0];
 #pragma unroll
-            for (int g6 = 0; g6 < 6; ++g6) {
-                const int gi = g6 & 1, term = g6 >> 1, gap = 6 * s + g6;
-                if (t > 0) {
-                    if (EPI == 1 && gap == 0) w2q = *reinterpret_cast<const f32x4*>(w2_l + mcnx3_tile_off(t - 1));
-                    if constexpr (STRIDE > 0) {
-                        if (gap >= START && (gap - START) % STRIDE == 0 && (gap - START) / STRIDE < NIT) item(acc[(t - 1) & 1], t - 1, (gap - START) / STRIDE);
-                    } else if (gap >= 1) {
+            for (int g = 0; g < 3; ++g) {
+                const int gap = 3 * s + g;
+                if (t > 0 && gap >= START) {
 #pragma unroll
-                        for (int k = (gap - 1) * IPG; k < gap * IPG; ++k)
-                            if (k < NIT) item(acc[(t - 1) & 1], t - 1, k);
-                    }
+                    for (int i = (gap - START) * IPG; i < (gap - START + 1) * IPG; ++i)
+                        if (i < NITG) item(acc[(t - 1) & 1], t - 1, i);
+                    if (STAG && gap >= SBASE && (gap - SBASE) / SSTR < NST && (gap - SBASE) % SSTR == 0)
+                        item(acc[(t - 1) & 1], t - 1, 8 * IPW + (gap - SBASE) / SSTR);
                 }
-                if (SAVE && gap == SG_H) {
-                    if (t >= 3 && (t & 1)) store_hi(0, (t - 3) / 2);
-                    if (t >= 4 && !(t & 1)) store_hi(1, (t - 4) / 2);
-                }
-                if (SV == 1 && gap == SG_L) {
-                    if (t >= 3 && (t & 1)) store_lo(0, (t - 3) / 2);
-                    if (t >= 4 && !(t & 1)) store_lo(1, (t - 4) / 2);
-                }
-                if (gap == BG && t + 1 < NT) bias_init(acc[(t + 1) & 1], t + 1);
-                mcnx3_gap_dma6<F, PPW>(ring, 6 * f + g6);
-                const u32x4_t b = s < KENC ? (term == 1 ? encl[gi][s < KENC ? s : 0] : ench[gi][s < KENC ? s : 0])
-                                           : (term == 1 ? inl[gi][s >= KENC ? s - KENC : 0] : inh[gi][s >= KENC ? s - KENC : 0]);
+                if (gap == BIAS_G && t + 1 < NT) bias_init(acc[(t + 1) & 1], t + 1);
+                mcnx3_gap_dma<F, PPW>(ring, 3 * f + g);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[t & 1][gi] = mcnx3_mfma16(term == 0 ? a_l : a_h, b, acc[t & 1][gi]);     // lo*hi, hi*lo, hi*hi
+                acc[t & 1] = mcnx3_mfma(g == 0 ? a_l : a_h, g == 1 ? b_l : b_h, acc[t & 1]);     // lo*hi, hi*lo, hi*hi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    mcnx3_layer_end6<F, PPW>(ring);
-    if (EPI == 1) w2q = *reinterpret_cast<const f32x4*>(w2_l + mcnx3_tile_off(NT - 1));
+    mcnx3_layer_end<F, PPW>(ring);
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) item(acc[(NT - 1) & 1], NT - 1, k);
+    for (int i = 0; i < NIT; ++i) item(acc[(NT - 1) & 1], NT - 1, i);
     if (SAVE) {
 #pragma unroll
-        for (int so = 0; so < KS2; ++so)
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi)
-                if (2 * so + 3 + gi > NT - 1) {              // (not stored inside the loop)
-                    store_hi(gi, so);
-                    if (!HI) store_lo(gi, so);
-                }
-        // ReLU bit words in the 32-row format: the word of (sample m, half h) is the OR of the nibbles of lanes (n, rg = h) and
-        // (n, rg = h + 2) of the sample's group; after the swap lanes 0-31 hold both nibbles of group 0, lanes 32-63 of group 1
-#pragma unroll
-        for (int i = 0; i < MW; ++i) {
-            mcnx3_swap32(mwd[0][i], mwd[1][i]);
-            mcn16_ws_store(mwd[0][i] | mwd[1][i], mask_lane + i);
-        }
+        for (int i = 0; i < MW; ++i) mcn16_ws_store(mw[i], mask_lane + i);
     }
 }
+
 
 template <int W, int SV>
 __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x3_fwd_kernel(Mcn16FwdArgs a) {
@@ -228,13 +159,11 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
     constexpr bool SAVE = SV != 0, HI = SV == 2;
     constexpr int PL = HI ? 1 : 2;                 // fragment planes per saved tile
     constexpr int WAVES = mcnx3_waves(W), ROWS = 32 * WAVES, PPW = 16 / WAVES;
-    constexpr int KS = W / 16, KS2 = W / 32, MW = W >= 64 ? W / 64 : 1;
+    constexpr int KS = W / 16, MW = W >= 64 ? W / 64 : 1;
     constexpr float SXW = MCNX3_SX * MCNX3_SW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, rg = lane >> 4, r1 = rg & 1, gown = lane >> 5;
-    const int m = 16 * gown + n;                   // the sample of the wave's 32-row tile this lane owns (twice: r1 = 0, 1)
-    const int lane32 = 32 * r1 + 16 * gown + n;    // position (32 h + m) of (m, h = r1) in the 32-row formats
+    const int m = lane & 31, h = lane >> 5;
     const int D = a.lay.depth, skip = a.lay.skip;
     const long long total = a.count ? (long long)min(*a.count, a.max_rows) : (long long)a.n_rays * a.S;
     if ((long long)blockIdx.x * ROWS >= total) return;
@@ -248,7 +177,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
     for (int i = tid; i < W; i += 64 * WAVES) {
         sbias[D * W + i] = a.params[a.lay.pBs1 + i] * SXW;
         sbias[(D + 1) * W + i] = a.params[a.lay.pBc1 + i] * SXW;
-        sw2[i] = a.params[a.lay.pWs2 + i] * (1.0f / MCNX3_SW);
+        sw2[i] = a.params[a.lay.pWs2 + i];
     }
     if (tid < 32) {      // sh.2 bias in the kernel's 27-row geometry (a degree below 2: the rows the net has, zero elsewhere)
         const int row = tid < MCN_NSH ? mcn_sh_row(tid, a.lay.sh_deg) : -1;
@@ -258,8 +187,6 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
     float bw[MCN_NFREQ];
 #pragma unroll
     for (int f = 0; f < MCN_NFREQ; ++f) bw[f] = a.barf_w[f];
-    const unsigned long long r1_mask = __builtin_amdgcn_ballot_w64(r1 != 0);
-    const float isw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / MCNX3_SW)));
     __syncthreads();
 
     // ---- per-sample inputs.  On the wide net (one wave per SIMD: nothing else covers a memory round trip) they are
@@ -305,12 +232,8 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
     Mcn16Ring ring;
     mcnx3_ring_start<PPW>(ring, smem, a.packed, a.stream_slabs, wave, lane);
 
-    // lane parts of the tile geometry: rows 4 rg .. 4 rg + 3 of a tile are channels mcnx3_tile_off(t2) + 16 (rg >> 1) + 4 (rg & 1) + i
-    const int lane_ch = 16 * gown + 4 * r1;
-    const float* bias_l = sbias + lane_ch;
-    const float* w2_l = sw2 + lane_ch;
-    const unsigned msh = 4u * (1u - (unsigned)gown);            // the nibble of a ReLU bit byte this lane's row group fills
-    const size_t chunk_off = (size_t)gown * 1024 + (32 * r1 + n) * 16;      // of group 0's chunk inside a k-step-of-32 pair of fragments
+    const float* bias_h = sbias + 4 * h;
+    const float* w2_h = sw2 + 4 * h;
 
     for (long long pass = blockIdx.x; pass * ROWS < total; pass += gridDim.x) {
         const long long tile = pass * WAVES + wave;             // global 32-row tile of this wave
@@ -318,7 +241,7 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
         const bool valid = g < total;
         const long long gc = valid ? g : total - 1;
         const long long pass_n = pass + gridDim.x;
-        // ---- per-sample setup (the lane's own sample; both copies of a sample compute the same values)
+        // ---- per-sample setup (lane-local; both lane halves of a sample compute the same values)
         int ray, j;
         float zv, dx, dy, dz, ox, oy, oz;
         if (PREF) {
@@ -345,72 +268,54 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
             mcn16_dma4(reinterpret_cast<const int*>(a.idx) + 2 * (gn < total ? gn : total - 1) + (lane & 1), idx_lds);
         }
         const int addr = ray * a.S + j;
-        // ---- encoded input fragments.  From its own sample a lane packs the chunks (k-step-of-16 2 s2, h = r1) and (2 s2 + 1, h = r1):
-        // the first is the fragment of row group r1 (lanes 0-31's own group-0 fragment, and what lanes 0-31 need of group 1 from their
-        // partner lane L + 32), the second that of row group r1 + 2 -- one swap of the wave halves per word puts each where it is used.
-        u32x4_t ench[2][MCNX3_ENCKS2], encl[2][MCNX3_ENCKS2];
+        u32x4_t ench[MCN16_ENCKS], encl[MCN16_ENCKS];
         {
             float E[64];
             mcnx3_encode_values(p, bw, E);
 #pragma unroll
-            for (int s2 = 0; s2 < MCNX3_ENCKS2; ++s2)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const int c0 = mcn16_chan(2 * s2 + u, 0, 2 * d), c1 = mcn16_chan(2 * s2 + u, 0, 2 * d + 1);
-                        unsigned wh, wl;
-                        mcnx3_split2(mcnx3_sel(E[c0], E[c0 + 4], r1_mask) * MCNX3_SX, mcnx3_sel(E[c1], E[c1 + 4], r1_mask) * MCNX3_SX, wh, wl);
-                        ench[u][s2][d] = wh; encl[u][s2][d] = wl;
-                    }
-#pragma unroll
-            for (int s2 = 0; s2 < MCNX3_ENCKS2; ++s2)
+            for (int s = 0; s < MCN16_ENCKS; ++s)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    unsigned x0 = ench[0][s2][d], x1 = ench[1][s2][d], y0 = encl[0][s2][d], y1 = encl[1][s2][d];
-                    mcnx3_swap32(x0, x1);
-                    mcnx3_swap32(y0, y1);
-                    ench[0][s2][d] = x0; ench[1][s2][d] = x1; encl[0][s2][d] = y0; encl[1][s2][d] = y1;
+                    const int c0 = mcn16_chan(s, 0, 2 * d), c1 = mcn16_chan(s, 0, 2 * d + 1);
+                    unsigned wh, wl;
+                    mcnx3_split2((h ? E[c0 + 4] : E[c0]) * MCNX3_SX, (h ? E[c1 + 4] : E[c1]) * MCNX3_SX, wh, wl);
+                    ench[s][d] = wh; encl[s][d] = wl;
                 }
         }
-        char* act_lane = SAVE ? reinterpret_cast<char*>(a.act_ws) + (size_t)tile * (PL * KS) * 1024 + chunk_off : nullptr;
-        unsigned* mask_lane = SAVE ? a.mask_ws + ((size_t)tile * 64 + lane32) * MW : nullptr;
+        char* act_lane = SAVE ? reinterpret_cast<char*>(a.act_ws) + (size_t)tile * (PL * KS) * 1024 + lane * 16 : nullptr;
+        unsigned* mask_lane = SAVE ? a.mask_ws + ((size_t)tile * 64 + lane) * MW : nullptr;
         if (SAVE) {
-            char* e = reinterpret_cast<char*>(a.enc_ws) + (size_t)tile * (PL * MCN16_ENCKS) * 1024 + chunk_off;
+            char* e = reinterpret_cast<char*>(a.enc_ws) + (size_t)tile * (PL * MCN16_ENCKS) * 1024 + lane * 16;
 #pragma unroll
-            for (int s2 = 0; s2 < MCNX3_ENCKS2; ++s2)
-#pragma unroll
-                for (int gi = 0; gi < 2; ++gi) {
-                    mcn16_ws_store(ench[gi][s2], reinterpret_cast<u32x4_t*>(e + s2 * 2048 + gi * 256));
-                    if (!HI) mcn16_ws_store(encl[gi][s2], reinterpret_cast<u32x4_t*>(e + MCN16_ENCKS * 1024 + s2 * 2048 + gi * 256));
-                }
+            for (int s = 0; s < MCN16_ENCKS; ++s) {
+                mcn16_ws_store(ench[s], reinterpret_cast<u32x4_t*>(e + s * 1024));
+                if (!HI) mcn16_ws_store(encl[s], reinterpret_cast<u32x4_t*>(e + (MCN16_ENCKS + s) * 1024));
+            }
         }
 
-        u32x4_t xah[2][KS2], xal[2][KS2], xbh[2][KS2], xbl[2][KS2];
-        float dot[2] = {0.f, 0.f};
+        u32x4_t xah[KS], xal[KS], xbh[KS], xbl[KS];
+        float dot = 0.f;
         // ---- layer 0 (encoded input only), then the trunk two layers per trip (xb -> xa -> xb: no copies between layers);
         //      the skip layer takes [encoding, hidden]
-        mcnx3_layer<W, SV, MCNX3_ENCKS2, 0, 0, PPW>(ring, smem, lane, isw, ench, encl, xah, xal, xbh, xbl, bias_l, nullptr, dot, act_lane, mask_lane, msh);
+        mcnx3_layer<W, SV, MCN16_ENCKS, 0, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h, nullptr, dot, act_lane, mask_lane);
         for (int l = 1; l < D; l += 2) {
             char* sl = SAVE ? act_lane + (size_t)l * a.slot_bytes : nullptr;
             unsigned* ml = SAVE ? mask_lane + (size_t)l * a.mask_slot_words : nullptr;
-            if (l == skip) mcnx3_layer<W, SV, MCNX3_ENCKS2, KS2, 0, PPW>(ring, smem, lane, isw, ench, encl, xbh, xbl, xah, xal, bias_l + l * W, nullptr, dot, sl, ml, msh);
-            else mcnx3_layer<W, SV, 0, KS2, 0, PPW>(ring, smem, lane, isw, ench, encl, xbh, xbl, xah, xal, bias_l + l * W, nullptr, dot, sl, ml, msh);
+            if (l == skip) mcnx3_layer<W, SV, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + l * W, nullptr, dot, sl, ml);
+            else mcnx3_layer<W, SV, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + l * W, nullptr, dot, sl, ml);
             if (l + 1 < D) {
                 sl = SAVE ? act_lane + (size_t)(l + 1) * a.slot_bytes : nullptr;
                 ml = SAVE ? mask_lane + (size_t)(l + 1) * a.mask_slot_words : nullptr;
-                if (l + 1 == skip) mcnx3_layer<W, SV, MCNX3_ENCKS2, KS2, 0, PPW>(ring, smem, lane, isw, ench, encl, xah, xal, xbh, xbl, bias_l + (l + 1) * W, nullptr, dot, sl, ml, msh);
-                else mcnx3_layer<W, SV, 0, KS2, 0, PPW>(ring, smem, lane, isw, ench, encl, xah, xal, xbh, xbl, bias_l + (l + 1) * W, nullptr, dot, sl, ml, msh);
+                if (l + 1 == skip) mcnx3_layer<W, SV, MCN16_ENCKS, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + (l + 1) * W, nullptr, dot, sl, ml);
+                else mcnx3_layer<W, SV, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xah, xal, xbh, xbl, bias_h + (l + 1) * W, nullptr, dot, sl, ml);
             } else {               // an even trunk depth ends in xa: one copy per pass
 #pragma unroll
-                for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-                    for (int s = 0; s < KS2; ++s) { xbh[gi][s] = xah[gi][s]; xbl[gi][s] = xal[gi][s]; }
+                for (int s = 0; s < KS; ++s) { xbh[s] = xah[s]; xbl[s] = xal[s]; }
             }
         }
         // ---- sigma head: hidden layer on the matrix pipe, the 1-wide output layer lane-local (on the fp32 activations)
-        mcnx3_layer<W, SV, 0, KS2, 1, PPW>(ring, smem, lane, isw, ench, encl, xbh, xbl, xah, xal, bias_l + D * W, w2_l, dot,
-                                             SAVE ? act_lane + (size_t)D * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)D * a.mask_slot_words : nullptr, msh);
+        mcnx3_layer<W, SV, 0, KS, 1, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + D * W, w2_h, dot,
+                                            SAVE ? act_lane + (size_t)D * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)D * a.mask_slot_words : nullptr);
         if (PREF) {                // the coming pass's rows: index pair from LDS, gathers by LDS-DMA (landed long before the pass ends)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_IDX) : "memory");
             if (a.idx) {
@@ -422,81 +327,63 @@ __global__ __launch_bounds__(64 * mcnx3_waves(W), mcnx3_waves(W) / 4) void mlp_x
             }
             gather_dma(ray_n, j_n);
         }
-        // ---- SH head: hidden layer (reads the same trunk output), then the 27 (32) coefficient rows as two tiles of 16
-        mcnx3_layer<W, SV, 0, KS2, 0, PPW>(ring, smem, lane, isw, ench, encl, xbh, xbl, xah, xal, bias_l + (D + 1) * W, nullptr, dot,
-                                             SAVE ? act_lane + (size_t)(D + 1) * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)(D + 1) * a.mask_slot_words : nullptr, msh);
-        f32x4 sacc[2][2];                          // [tile u][group]: rows 16 (rg >> 1) + 8 u + 4 (rg & 1) + i of the sh.2 outputs
+        // ---- SH head: hidden layer (reads the same trunk output), then the 27 (32) coefficient rows
+        mcnx3_layer<W, SV, 0, KS, 0, PPW>(ring, smem, lane, ench, encl, xbh, xbl, xah, xal, bias_h + (D + 1) * W, nullptr, dot,
+                                            SAVE ? act_lane + (size_t)(D + 1) * a.slot_bytes : nullptr, SAVE ? mask_lane + (size_t)(D + 1) * a.mask_slot_words : nullptr);
+        f32x16 acc;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(sbc2 + lane_ch + 8 * u);
-            sacc[u][0] = b; sacc[u][1] = b;
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sbc2 + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * q + e] = b[e];
         }
         {
             Mcn16Cursor cur;
 #pragma unroll
-            for (int f = 0; f < 2 * KS2; ++f) {
-                const int u = f / KS2, s = f % KS2;
-                mcnx3_before_mfma<2 * KS2, PPW>(ring, cur, f);
-                const unsigned o = cur.cur + (f & (MCNX3_SLABF - 1)) * 2048 + lane * 16;
+            for (int s = 0; s < KS; ++s) {
+                mcnx3_before_mfma<KS, PPW>(ring, cur, s);
+                const unsigned o = cur.cur + (s & (MCNX3_SLABF - 1)) * 2048 + lane * 16;
                 const u32x4_t a_h = *reinterpret_cast<const u32x4_t*>(smem + o);
                 const u32x4_t a_l = *reinterpret_cast<const u32x4_t*>(smem + o + 1024);
-#pragma unroll
-                for (int g6 = 0; g6 < 6; ++g6) {
-                    const int gi = g6 & 1, term = g6 >> 1;
-                    sacc[u][gi] = mcnx3_mfma16(term == 0 ? a_l : a_h, term == 1 ? xal[gi][s] : xah[gi][s], sacc[u][gi]);
-                }
+                mcnx3_mfma3(acc, a_h, a_l, xah[s], xal[s]);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int e = 0; e < 16; ++e) acc[e] *= 1.0f / SXW;
+        if (SAVE) {          // the SH coefficients (bias included) for the backward's view-direction term: the fp32 accumulator tile
+            char* e = reinterpret_cast<char*>(a.sh_ws) + (size_t)tile * 4096 + lane * 16;
 #pragma unroll
-            for (int gi = 0; gi < 2; ++gi) sacc[u][gi] *= 1.0f / SXW;
-        if (SAVE) {          // the SH coefficients (bias included) for the backward's view-direction term: the fp32 accumulator tile of the
-            //                   32-row form, whose quad q = 2 (rg >> 1) + u of lane (m, h = rg & 1) this is
-            char* e = reinterpret_cast<char*>(a.sh_ws) + (size_t)tile * 4096 + (size_t)gown * 2048 + (32 * r1 + n) * 16;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int gi = 0; gi < 2; ++gi)
-                    mcn16_ws_store(sacc[u][gi], reinterpret_cast<f32x4*>(e + u * 1024 + gi * 256));
+            for (int q = 0; q < 4; ++q)
+                mcn16_ws_store(f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]}, reinterpret_cast<f32x4*>(e + q * 1024));
         }
-        // ---- per-sample epilogue: sigma, SH colour (model/net_utils.py:154-169), sigmoid.  Accumulator i of tile u is SH row
-        //      16 (rg >> 1) + 8 u + 4 (rg & 1) + i = 9 c + b (colour c, basis b) of the group's sample; group gi's direction is the
-        //      lane's own where gi == L >> 5, its partner's (L ^ 32) otherwise.
-        float dox = dx, doy = dy, doz = dz, dpx = dx, dpy = dy, dpz = dz;
-        mcnx3_swap32(dox, dpx); mcnx3_swap32(doy, dpy); mcnx3_swap32(doz, dpz);
-        // (after the swap: lanes 0-31: do* = own (group 0), dp* = partner's (group 1); lanes 32-63: do* = partner's (group 0), dp* = own (group 1))
-        float pre[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        // ---- per-sample epilogue: sigma, SH colour (model/net_utils.py:154-169), sigmoid.  Register 4q + e of this lane
+        //      is SH row n = 8q + 4h + e = 9 c + i (colour c, basis i); the two lane halves hold complementary rows.
+        float bas[9];
+        mcn_sh_basis(dx, dy, dz, bas);
+        float pre[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            float bas[9];
-            if (gi == 0) mcn_sh_basis(dox, doy, doz, bas);
-            else mcn_sh_basis(dpx, dpy, dpz, bas);
+        for (int r = 0; r < 16; ++r) {
+            const int n0 = 8 * (r >> 2) + (r & 3), n1 = n0 + 4;
+            const float b0 = n0 < MCN_NSH ? bas[n0 % 9] : 0.f, b1 = n1 < MCN_NSH ? bas[n1 % 9] : 0.f;
+            const float contrib = acc[r] * (h ? b1 : b0);
+            const int c0 = n0 / 9, c1 = n1 / 9;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {          // the four row groups hold different rows in this register
-                        const int row = 16 * (v >> 1) + 8 * u + 4 * (v & 1) + i;
-                        if (row < MCN_NSH) pre[gi][row / 9] = fmaf(sacc[u][gi][i], rg == v ? bas[row % 9] : 0.f, pre[gi][row / 9]);
-                    }
+            for (int c = 0; c < 3; ++c) {
+                const bool in0 = n0 < MCN_NSH && c0 == c, in1 = n1 < MCN_NSH && c1 == c;
+                if (in0 && in1) pre[c] += contrib;
+                else if (in0) pre[c] += h ? 0.f : contrib;
+                else if (in1) pre[c] += h ? contrib : 0.f;
+            }
         }
-        // sums over the four row groups of a sample; a lane ends with its OWN sample's values (lanes 0-31: group 0, 32-63: group 1)
-        float own[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float x0 = c < 3 ? pre[0][c] : dot[0], x1 = c < 3 ? pre[1][c] : dot[1];
-            mcnx3_swap32(x0, x1);
-            const float sown = x0 + x1;
-            own[c] = sown + __shfl_xor(sown, 16);
-        }
-        const float sigma = own[3] * (1.0f / MCNX3_SX) + bs2;
+        const float sigma = (dot + __shfl_xor(dot, 32)) * (1.0f / MCNX3_SX) + bs2;
         f32x4 o;
         o[0] = sigma;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[1 + c] = 1.0f / (1.0f + expf(-own[c]));
-        if (valid && r1 == 0) *reinterpret_cast<f32x4*>(a.out + (size_t)addr * 4) = o;
+        for (int c = 0; c < 3; ++c) {
+            const float pc = pre[c] + __shfl_xor(pre[c], 32);
+            o[1 + c] = 1.0f / (1.0f + expf(-pc));
+        }
+        if (valid && h == 0) *reinterpret_cast<f32x4*>(a.out + (size_t)addr * 4) = o;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ring pieces still in flight must land before the LDS is released
 }

@@ -74,37 +74,32 @@ hipError_t mcn16_launch_pack(const McnLayout& L, const float* params, void* pack
 // ---- split-f16 ("f16x3") streams (mcnerf_x3.h): per logical fragment the hi piece (f16(w SW)) then the lo piece
 //      (f16(w SW - hi)), segments padded to whole slabs of 8 logical fragments.
 #include "mcnerf_x3.h"
-// GEO16F / GEO16B: the stream is laid out for the 16 x 16 x 32 form of its chain (mcnerf_x3.h): a 32-row tile of the segment
-// description is two tiles of 16 rows (row r of tile t2 = channel mcnx3_row16(t2, r)), a pair of k-steps one k-step of 32
-// (contraction position (s2, rg, j) = channel mcnx3_chan32(s2, rg, j)); the same fragments in number and size.
-template <bool GEO16F, bool GEO16B>
 __global__ void packx3_kernel(Mcn16Stream sf, Mcn16Stream sb, const float* __restrict__ params, char* __restrict__ pf, char* __restrict__ pb, unsigned* flags) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nf = sf.total_frags * 64, nb = sb.total_frags * 64;
     if (gid >= nf + nb) return;
     const bool bwd = gid >= nf;
-    const bool geo16 = bwd ? GEO16B : GEO16F;
     const Mcn16Stream& st = bwd ? sb : sf;
     const int id = bwd ? gid - nf : gid;
     const int frag = id >> 6, lane = id & 63;
+    const int i = lane & 31, h = lane >> 5;
     int s = 0;
     while (s + 1 < st.nseg && frag >= st.seg[s + 1].first_frag) ++s;
     const Mcn16Seg sg = st.seg[s];
     const int loc = frag - sg.first_frag;
-    const int div = geo16 ? 2 : 1;
-    const int per_tile = (sg.a.ksteps + sg.b.ksteps) / div, aks = sg.a.ksteps / div;
+    const int per_tile = sg.a.ksteps + sg.b.ksteps;
     const int t = loc / per_tile, ks = loc - t * per_tile;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    if (t < sg.tiles * div) {
-        const bool inb = ks >= aks;
+    if (t < sg.tiles) {
+        const bool inb = ks >= sg.a.ksteps;
         const Mcn16Part p = inb ? sg.b : sg.a;
-        const int kk = inb ? ks - aks : ks;
-        const int o = geo16 ? mcnx3_row16(t, lane & 15) : 32 * t + (lane & 31);
+        const int kk = inb ? ks - sg.a.ksteps : ks;
+        const int o = 32 * t + i;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = geo16 ? mcnx3_chan32(kk, lane >> 4, j) : mcn16_chan(kk, lane >> 5, j);
+            const int c = mcn16_chan(kk, h, j);
             if (o < p.out_real && c < p.con_real) v[j] = mcn16_pack_src(params, p, sg.transposed, o, c);
         }
     }
@@ -125,6 +120,6 @@ hipError_t mcnx3_launch_pack(const McnLayout& L, const float* params, void* pack
     const Mcn16Stream sf = mcnx3_fwd_stream(L), sb = mcnx3_bwd_stream(L);
     const int total = (sf.total_frags + sb.total_frags) * 64;
     const int threads = 256, grid = (total + threads - 1) / threads;
-    hipLaunchKernelGGL((packx3_kernel<MCNX3_FWD_GEO16, MCNX3_BWD_GEO16>), dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd, flags);
+    hipLaunchKernelGGL(packx3_kernel, dim3(grid), dim3(threads), 0, st, sf, sb, params, (char*)packed_fwd, (char*)packed_bwd, flags);
     return hipGetLastError();
 }

@@ -37,7 +37,7 @@ def _device_elf(obj, tmp_path):
 def test_m0_is_written_only_by_the_ring_asm(obj, tmp_path):
     elf = _device_elf(obj, str(tmp_path))
     dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", elf], check=True, capture_output=True, text=True).stdout
-    assert dis.count("v_mfma_f32_32x32x16_f16") + dis.count("v_mfma_f32_16x16x32_f16") > 1000
+    assert dis.count("v_mfma_f32_32x32x16_f16") > 1000
     bad = []
     for line in dis.splitlines():
         ins = line.split("//")[0].strip()
@@ -128,3 +128,50 @@ def test_scratch_stays_out_of_the_mfma_loops(obj, tmp_path):
         if obj != "mlp_x3_dw.o":      # chains: the pass loop contains everything; <= 20 scratch operations per pass (of >= 600 MFMAs)
             assert len(in_loop) <= 20, f"{name}: {len(in_loop)} scratch operations per pass"
     assert seen == len(KNOWN_SCRATCH[obj])
+
+
+# ---- product-build hygiene (review item 7): the library is ONE build of ONE source text -- no timing-only / ablation / experiment
+#      switches live in the product sources or in the build flags, and nothing but the declared C ABI is exported
+ALLOWED_PP_NAMES = {"__HIPCC__"}
+
+
+def test_no_ablation_or_experiment_switches_in_the_product_sources():
+    """Every preprocessor conditional of mc_nerf_amd/csrc tests a name of ALLOWED_PP_NAMES and nothing else (round 5 carried 32
+    `ABL*` / `MCN*_EXP_*` / `*_STAMPS` knobs in the kernel sources; their records are in the history and under profiles/)."""
+    csrc = os.path.join(ROOT, "mc_nerf_amd", "csrc")
+    bad = []
+    for fn in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h"))):
+        for n, line in enumerate(open(os.path.join(csrc, fn)).read().split("\n"), 1):
+            m = re.match(r"\s*#\s*(ifdef|ifndef|if|elif)\b(.*)", line)
+            if not m:
+                continue
+            names = set(re.findall(r"[A-Za-z_]\w*", re.sub(r"//.*", "", m.group(2)))) - {"defined"}
+            if not names <= ALLOWED_PP_NAMES:
+                bad.append(f"{fn}:{n}: {line.strip()}")
+    assert not bad, "preprocessor switches in the product sources:\n" + "\n".join(bad)
+
+
+def test_build_flags_define_nothing():
+    from mc_nerf_amd import build
+    flags = list(build.FLAGS) + [f for fl in build.FILE_FLAGS.values() for f in fl]
+    assert not [f for f in flags if f.startswith("-D") or f.startswith("-U")], flags
+
+
+def test_library_exports_only_the_declared_abi():
+    """`nm -D` of the built library: every exported mcnerf_* symbol is declared in include/mcnerf.h (no mcnerf_debug_* / stamp
+    read-back entry points), and no variant library or variant object directory ships beside it."""
+    lib = os.path.join(ROOT, "mc_nerf_amd", "libmcnerf.so")
+    if not os.path.isfile(lib) or shutil.which("nm") is None:
+        pytest.skip("no built library / nm")
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], check=True, capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mcnerf.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(mcnerf_[a-z_0-9]+)\s*\(", hdr))
+    extra = {s for s in exported if s.startswith("mcnerf_")} - declared
+    assert not extra, f"exported but not declared: {sorted(extra)}"
+    assert not [s for s in exported if "debug" in s.lower() or "stamp" in s.lower()]
+    strings = subprocess.run(["strings", "-n", "6", lib], capture_output=True, text=True).stdout if shutil.which("strings") else ""
+    assert "mcnerf_debug_stamps" not in strings and "g_mcnx3_fstamps" not in strings
+    pkg = os.path.join(ROOT, "mc_nerf_amd")
+    tracked = subprocess.run(["git", "ls-files", pkg], capture_output=True, text=True, cwd=ROOT).stdout
+    assert "libmcnerf_" not in tracked and "build_" not in tracked
