@@ -49,14 +49,14 @@ ALGO_BYTES_PER_RAY = 100
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0      # ibid., "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0              # ibid., "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured float4 copy)
-# The two unit costs of DESIGN.md 3.6's energy budget, measured on this pool (NOT vendor figures): what a bare
+# The two unit costs of NOTES.md §3.6's energy budget, measured on this pool (NOT vendor figures): what a bare
 # v_mfma_f32_32x32x16_f16 loop sustains on random operands under the chip's power management (profiles/r05k_mfma_shape.txt,
 # r05_mfma_peak.txt: 1.71-1.74 PF/s), and what a gigabyte written by a chain costs at unchanged cycle counts (saving minus
 # no-save forward: 1.6 ms for 18.3 GB in f16x3h, 1.6 ms for 18.1 GB in f16; profiles/r05f_ablate_storewin.txt, r05_cfg5_bf16_spread.txt)
 BARE_MFMA_TFLOPS_RANDOM = 1720.0
 CHAIN_WRITE_MS_PER_GB = 0.085
 MFMAS_PER_PRODUCT = {"f16x3h": (3, 3, 1), "f16x3": (3, 3, 3), "f16": (1, 1, 1), "bf16": (1, 1, 1)}      # forward chain, dX chain, weight gradient
-# HBM bytes per evaluated fine sample that each kernel's CONTRACT makes it move (DESIGN.md 3).
+# HBM bytes per evaluated fine sample that each kernel's CONTRACT makes it move (DESIGN.md 4).
 #  fp32 / split-f16 words: 10 layer slots x 256 x 4 B (+ encoding 256, SH 128, 1-bit masks 320, output 16, index 8)
 B32 = {"fwd": 10 * 1024 + 256 + 128 + 320 + 16 + 8,
        "bwd": 10 * 1024 + 128 + 320 + 256 + 128 + 32 + 8,
@@ -222,7 +222,7 @@ def parity_probe(precisions, dev):
     """One small train render + backward (256 rays, cfg-2 nets at random init, the same draws) in each of `precisions` against the fp32
     CPU oracle: max |rgb - oracle|, and of the 40 parameter gradients the worst and the median error relative to the tensor's
     largest oracle gradient -- what each mode's arithmetic costs on the bench's own nets.  (The reference's own fp32 gradients move
-    by 2.5e-5 median / 1.7e-3 worst of a tensor's max under a re-ordering of its sums at 2048 rays: DESIGN.md 4.)
+    by 2.5e-5 median / 1.7e-3 worst of a tensor's max under a re-ordering of its sums at 2048 rays: NOTES.md §4.)
     -> the first mode's record, with the other modes' records under their names."""
     import torch
     from mc_nerf_amd.model import NeRF_Model, MC_NeRF_Loss
@@ -258,8 +258,19 @@ def parity_probe(precisions, dev):
                            "rgb_f_max_abs_err": float((rgb_f.detach().cpu() - r["rgb_f"].detach()).abs().max()),
                            "grad_worst_rel_to_tensor_max": rel[-1], "grad_median_rel_to_tensor_max": rel[len(rel) // 2]}
     out = dict(recs[precisions[0]])
-    out["what"] = ("train render + backward of 256 rays, random-init cfg-2 nets, same draws, vs the fp32 CPU oracle: colours; the 40 parameter "
-                   "gradients (max error of a tensor / its largest oracle gradient: worst and median tensor)")
+    # the yardstick of the gradient columns: what the ACTUAL reference's fp32 gradients do under a re-ordering of its own sums
+    # (fixture data of tests/golden/g7_train_s64x2_full2048.npz: worst / median over the same 40 tensors); smoke() gates on multiples of it
+    from __graft_entry__ import reorder_noise, PARITY_GATES
+    n_worst, n_median = reorder_noise()
+    out["reference_reorder_noise"] = {"worst": n_worst, "median": n_median}
+    for p_ in precisions:
+        recs[p_]["grad_worst_over_noise"] = recs[p_]["grad_worst_rel_to_tensor_max"] / n_worst
+        recs[p_]["grad_median_over_noise"] = recs[p_]["grad_median_rel_to_tensor_max"] / n_median
+        recs[p_]["gate_multiples"] = list(PARITY_GATES[p_][1:])
+    out.update({k: recs[precisions[0]][k] for k in ("grad_worst_over_noise", "grad_median_over_noise", "gate_multiples")})
+    out["what"] = ("train render + backward of 256 rays, random-init cfg-2 nets, same draws, vs the fp32 CPU oracle: colours; ALL 40 parameter "
+                   "gradients (max error of a tensor / its largest oracle gradient: worst and median tensor), also as multiples of the "
+                   "reference's own reorder noise on its at-size fixture")
     for p_ in precisions[1:]:
         out[p_] = recs[p_]
     return out
@@ -307,7 +318,9 @@ def compact_line(full, full_name="bench_full.json"):
             if p in pr:
                 gp[p] = [sig(pr[p]["grad_worst_rel_to_tensor_max"], 2), sig(pr[p]["grad_median_rel_to_tensor_max"], 2)]
         line["parity"] = {"rgb_max_abs_err": sig(max(pr["rgb_c_max_abs_err"], pr["rgb_f_max_abs_err"]), 2),
-                          "gradient_parity": gp, "what": "256 rays vs fp32 CPU oracle; gradients: [worst, median] tensor error / tensor max"}
+                          "gradient_parity": gp, "what": "256 rays vs fp32 CPU oracle; gradients of all 40 tensors: [worst, median] tensor error / tensor max"}
+        if "reference_reorder_noise" in pr:
+            line["parity"]["reference_reorder_noise"] = [sig(pr["reference_reorder_noise"]["worst"], 2), sig(pr["reference_reorder_noise"]["median"], 2)]
     for k in ("allreduce_ms", "rank_ms_per_step", "params_identical_across_ranks", "asymmetric_grad_steps", "valid", "skipped_optimizer_steps"):
         if k in full:
             v = full[k]["all"] if isinstance(full[k], dict) and "all" in full[k] else full[k]      # (rank_ms_per_step: every rank's own time)
@@ -572,7 +585,7 @@ def pmc_traffic(precision, kernel_key):
 
 
 def design_floor(precision, head, k_mean, rays, samples, coarse):
-    """the floor THIS design has on this chip -- the chains' executed MFMA work at the bare loop's rate + their PMC-measured
+    """NOTES.md §3.6: the floor THIS design has on this chip -- the chains' executed MFMA work at the bare loop's rate + their PMC-measured
     written bytes at the measured cost per gigabyte + the (HBM-bound) weight-gradient kernels and everything else as measured in this
     run.  None without a PMC recording of the current kernel sources, and for the exact-fp32 mode (other instructions)."""
     m = MFMAS_PER_PRODUCT.get(precision)
@@ -595,7 +608,7 @@ def design_floor(precision, head, k_mean, rays, samples, coarse):
     return {"chains_executed_tflop": chain_tflop, "chains_mfma_ms": chain_ms, "chains_written_GB": written / 1e9, "chains_write_ms": write_ms,
             "dw_measured_ms": dw_ms, "other_measured_ms": other_ms, "floor_ms": floor, "measured_ms": head["ms_per_step"],
             "measured_over_floor": head["ms_per_step"] / floor, "floor_over_measured": floor / head["ms_per_step"],
-            "what": "builder's energy budget of the step (DESIGN.md 3.6), NOT the contract's roofline: executed MFMA work of the chains at "
+            "what": "builder's energy budget of the step (NOTES.md §3.6), NOT the contract's roofline: executed MFMA work of the chains at "
                     f"{BARE_MFMA_TFLOPS_RANDOM:.0f} TFLOP/s (bare loop, random operands, this pool) + their written bytes at {CHAIN_WRITE_MS_PER_GB} ms/GB "
                     "+ the HBM-bound weight-gradient kernels and the small kernels as measured"}
 

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * MCN16_WAVES, 2) void mlp16_bwd_kernel(Mcn16Bwd
 
     // ---- the per-sample inputs of a pass are fetched ONE PASS AHEAD (software pipeline over the persistent loop): a pass
     // starts with two dependent gathers (index pair -> ray / output rows) behind every store of the previous pass in the
-    // in-order vmcnt queue, 15.8 k of the 150 k cycles of a pass when taken at the top (in-kernel stamps).
+    // in-order vmcnt queue, 15.8 k of the 150 k cycles of a pass when taken at the top (in-kernel stamps, NOTES.md §3.1).
     // The index pairs of pass p + 1 go to LDS by DMA right after the prologue of pass p; the row gathers are issued
     // when the GEMMs of pass p are done and land under its encoding backward.
     struct In { int ray; float zg, jit; f32x4 o, go; float dx, dy, dz, ox, oy, oz; };

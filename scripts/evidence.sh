@@ -26,7 +26,7 @@ for P in f16x3h f16x3; do
   python3 scripts/pmc_sq_summary.py gpurun_out/sq_$TAG > gpurun_out/${TAG}_sq_counters_$P.txt 2>&1
 done
 ls -la gpurun_out | tail -20
-# ---- the other workload shapes of BASELINE.json / DESIGN.md 5 (headline mode unless said otherwise), one JSON line each
+# ---- the other workload shapes of BASELINE.json / NOTES.md §5 (headline mode unless said otherwise), one JSON line each
 B="python3 bench.py --also= --occupancy= --no-extra --no-cpu-baseline --steps 20 --warmup 3"
 for RIG in array halfball room; do $B --rig $RIG 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_rig_$RIG.json; done
 # (N = 7000, the reference's 128 x 5 shape, the 8x256 coarse variant and render mode are `extra_lines` of the default line)

@@ -27,6 +27,30 @@ GATES = {"f32": (1e-4, 1e-4, 1e-4), "f16x3": (1e-4, 1e-4, 3e-4), "f16x3h": (1e-4
 SMALL_K, SMALL_K_GRAD_FACTOR = 1000, {"f16": 2.0}
 
 
+STATS = {}       # per mode: (rgb_c, rgb_f, parameter-gradient, ray-gradient error, fine samples) of every case run in this process
+
+
+def distribution_report():
+    """Per mode: how the sweep's errors are DISTRIBUTED (median / 90th / 99th percentile / worst), beside the gate -- the record a gate
+    change has to be argued from (review: 'record the fuzz's per-mode error distribution before touching a gate')."""
+    lines = []
+    for mode in sorted(STATS):
+        rows = torch.tensor(STATS[mode], dtype=torch.float64)
+        n = rows.shape[0]
+        q = lambda col, f: float(rows[:, col].sort().values[min(n - 1, int(f * n))])
+        g = GATES[mode]
+        small = int((rows[:, 4] < SMALL_K).sum())
+        for name, col, gate in (("colours", None, g[0]), ("parameter gradients", 2, g[1]), ("ray gradients", 3, g[2])):
+            if col is None:
+                v = torch.maximum(rows[:, 0], rows[:, 1]).sort().values
+                qs = [float(v[min(n - 1, int(f * n))]) for f in (0.5, 0.9, 0.99)] + [float(v[-1])]
+            else:
+                qs = [q(col, 0.5), q(col, 0.9), q(col, 0.99), float(rows[:, col].max())]
+            lines.append(f"  {mode:7s} {name:20s} n={n:4d}  median {qs[0]:.1e}  p90 {qs[1]:.1e}  p99 {qs[2]:.1e}  worst {qs[3]:.1e}   gate {gate:.1e}"
+                         + (f" (x {SMALL_K_GRAD_FACTOR[mode]:g} on the {small} cases below {SMALL_K} fine samples)" if col == 2 and mode in SMALL_K_GRAD_FACTOR else ""))
+    return "\n".join(lines)
+
+
 def one_case(rng, dev, verbose=True, general=False, modes=("f32", "f16x3")):
     """One random configuration.  `general`: any depth 1 ... 8, 0 ... 3 skip layers anywhere, SH degree 0 ... 3, 1 ... 10 encoding
     frequencies (model/net_block.py:10-18, 40-65) -- in any mode when the net has at most one skip layer and a degree <= 2, in the
@@ -128,6 +152,7 @@ def one_case(rng, dev, verbose=True, general=False, modes=("f32", "f16x3")):
         a_, b_ = set(key(kept).tolist()), set(key(full).tolist())
         print(f"     selection: device {k} (distinct {len(a_)}), oracle {full.shape[0]}, only device {sorted(a_ - b_)[:6]}, only oracle {sorted(b_ - a_)[:6]}, "
               f"same order {bool(k == full.shape[0] and torch.equal(kept, full))}", flush=True)
+    STATS.setdefault(precision, []).append((errs["rgb_c"], errs["rgb_f"], gerr, rerr, k))
     if verbose or not ok:
         print(("ok  " if ok else "FAIL"), desc, f"rgb {errs['rgb_c']:.1e}/{errs['rgb_f']:.1e} sel {sel_ok} K={k} grad {gerr:.1e} rays {rerr:.1e}{note}", flush=True)
     return ok
@@ -140,3 +165,5 @@ if __name__ == "__main__":
     allm = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("f32", "f16x3", "f16x3h", "f16", "bf16")
     res = [one_case(rng, dev, general=(i % 3 == 2), modes=allm) for i in range(cases)]
     print(f"{sum(1 for x in res if x is True)} ok, {sum(1 for x in res if x is False)} failed of {cases} (every third case a general topology)")
+    print("error distribution per mode (errors as gated: colours absolute, gradients relative to max(1, |g|max) of the tensor):")
+    print(distribution_report())

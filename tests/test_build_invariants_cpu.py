@@ -6,7 +6,7 @@
     MFMA gaps rely on it surviving compiler-scheduled code in between.  Every M0 write in those kernels must therefore be one of
     the inline-asm forms -- `s_mov_b32 m0, sN` (the refill; the save / set / restore sandwich of the one-off LDS-DMA helpers) --
     and nothing may use M0 implicitly (`s_set_gpr_idx*`, `v_movrel*`, `s_sendmsg`, GWS / `ds_*` addressing through M0).
-  * No scratch in the MFMA chains: a spilled fragment array is a silent 10x (it happened twice: DESIGN.md 3.1 / 3.2).  The
+  * No scratch in the MFMA chains: a spilled fragment array is a silent 10x (it happened twice: NOTES.md §3.1 / 3.2).  The
     kernels that DO spill are listed with their counts so that a change is seen.
 """
 import os

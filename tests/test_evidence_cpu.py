@@ -99,7 +99,7 @@ def test_pmc_traffic_belongs_to_the_sources_in_the_tree(precision):
 
 
 def test_design_floor_of_the_committed_record():
-    """`roofline.design_floor`: the budget is the sum of its parts, built from this run's own kernel times and the
+    """`roofline.design_floor` (NOTES.md §3.6): the budget is the sum of its parts, built from this run's own kernel times and the
     PMC-written bytes, and it stays BELOW the measured step (a floor that a measurement beats is a wrong floor)."""
     import bench
     path, d = _latest_default_line()

@@ -258,7 +258,7 @@ def test_sh_degree_topology_matches_reference(gpu_device, name, precision):
 
 
 # per mode: (rgb abs, worst per-tensor gradient error as a multiple of the reference's own worst reorder noise, median over the
-# tensors likewise against the noise's median) -- measured f32 0.8 / 1.2, f16x3 1.8 / 16, f16 / bf16 their operand rounding
+# tensors likewise against the noise's median) -- measured f32 0.8 / 1.2, f16x3 1.8 / 16 (NOTES.md §4), f16 / bf16 their operand rounding
 FULL_TOL = {"f32": (1e-4, 2.0, 3.0), "f16x3": (1e-4, 4.0, 40.0), "f16x3h": (1e-4, 4.0, 40.0), "f16": (5e-5, 60.0, 1500.0), "bf16": (4e-4, 300.0, 8000.0)}
 
 

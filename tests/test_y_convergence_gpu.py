@@ -7,7 +7,7 @@ blobs, 110-camera Ball rig; no dataset exists in the container), a few hundred s
     losses (mean of the last 50 steps) within 40 %.  (Three runs of this test: f16x3 23.6 / 23.0 / 23.8 dB, f32 22.7 / 23.7 /
     22.0 dB -- repeated runs of ONE mode differ by up to 1.7 dB: the weight-gradient atomics add in a different order every run
     and the trajectories part ways chaotically after a few hundred steps, so a tighter gate between the modes would measure
-    that, not the arithmetic; DESIGN.md 5.);
+    that, not the arithmetic; NOTES.md §5.);
   * GLOBAL_OPTIM joint camera + field stage through MC_Model (BARF mask on, cameras started off the ground truth): the
     mean rotation error decreases.
 """
