@@ -30,6 +30,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (this pool's host driver supports dmabuf IPC only: RCCL between rank processes needs it, and it has to be in the environment before
+#  anything touches HIP; the image exports it already -- this is for a launcher that scrubs the environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # algorithmic FLOPs per evaluated sample, forward: 2 x weight MACs.  The backward chain (dX) and the
 # weight gradients (dW) are one forward-equivalent each: a training step is 3x forward.
