@@ -150,14 +150,17 @@ int mcnerf_mlp_dw(int depth, int width, int skip, const int32_t* count, int rows
  *       gradients are bit-identical to dtype 2's -- but only the HI plane of every saved operand is written (in dtype 0's
  *       workspace layout: 2 bytes per value), and mcnerf_mlp_dw_16 is dtype 0's single-pass f16 kernel on those planes
  *       (activations carry the chains' 2^3 scale): the weight-gradient operands are rounded to 11 significand bits, everything
- *       that reaches a colour or a dX stays at 22.  Weight gradients differ from dtype 2's by <= 6e-4 of a tensor's largest
- *       entry (unbiased rounding of the operands); against the reference's own gradients the two modes measure the same
- *       (DESIGN.md 2).  Packed weights and the sh.2-output workspace (which 4) as dtype 2, the other workspaces as dtype 0.
- *       GATE of this mode (one statement, the same in DESIGN.md 2, README.md and the tests): rendered colours / depth /
- *       opacity, the selection list and the ray (camera) gradients meet dtype 2's 1e-4 bar -- they are dtype 2's bits; the
- *       PARAMETER gradients are gated at 6e-4 of a tensor's largest entry (measured 3.5e-4 in smoke(), 1.2e-5 in dtype 2):
- *       they do NOT meet dtype 2's 1e-4 bar.  bench.py reports this mode as its headline with dtype 2's line beside it
- *       (`f16x3_value`) and both modes' measured gradient errors (`parity.gradient_parity`).
+ *       that reaches a colour or a dX stays at 22.  Packed weights and the sh.2-output workspace (which 4) as dtype 2, the
+ *       other workspaces as dtype 0.
+ *       GATE of this mode (ONE statement; DESIGN.md 2, README.md, smoke() and the tests say the same): rendered colours /
+ *       depth / opacity, the selection list and the ray (camera) gradients meet dtype 2's 1e-4 bar -- they are dtype 2's
+ *       bits.  The PARAMETER gradients do NOT: (i) against dtype 2's they are gated at 1e-3 of a tensor's largest entry
+ *       (tests/test_model_gpu.py::test_f16x3h_runs_the_f16x3_chains; measured <= 6e-4: unbiased rounding of the dW operands to
+ *       11 bits); (ii) against the fp32 oracle, over ALL 40 tensors, at the multiples of the reference's own reorder noise
+ *       that dtype 2 is gated at -- worst tensor <= 4 x 1.7e-3, median tensor <= 40 x 2.2e-5 of a tensor's largest entry
+ *       (__graft_entry__.PARITY_GATES; measured at 256 rays: 2.5e-3 / 9.8e-5, dtype 2: 2.4e-3 / 3.0e-5, exact fp32: 1.4e-3 / 1.6e-5).
+ *       bench.py reports this mode as its headline with dtype 2's line beside it (`f16x3_value`) and every mode's measured
+ *       gradient errors (`parity.gradient_parity`).
  * Same reference code replaced as the fp32 entry points above (model/net_block.py:20-35, 67-78;
  * model/net_utils.py:103-191; model/mc_nerf.py:688-701).
  * Packed weights are two fragment STREAMS (forward order, backward = transposed order); workspaces are
