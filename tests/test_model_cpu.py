@@ -183,3 +183,27 @@ def test_bench_self_launches_its_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest"], env=env2,
                         capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and "--gpus 2" in (r2.stderr + r2.stdout)
+
+
+def test_bench_under_the_drivers_torchrun_command():
+    """The driver's N > 1 launch, verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- the ranks are torchrun's processes (bench.py must NOT start its own), they read RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, and rank 0 prints the one line (`--selftest`: rendezvous + all-reduce
+    over gloo, no kernels)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCNERF_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                   # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["allreduce_ok"] and out["backend"] == "gloo"
