@@ -160,6 +160,35 @@ def test_bench_under_torchrun_with_one_rank_is_the_plain_line(gpu_device, tmp_pa
     assert abs(a - b) < 0.5 * max(a, b), (a, b)           # (a 2048-ray step is ~2.5 ms and host-bound: a loose gate -- the claim is the PATH, checked above)
 
 
+@pytest.mark.timeout(460)
+def test_bench_under_the_drivers_torchrun_command_with_two_ranks(gpu_device, tmp_path):
+    """The driver's N > 1 launch, verbatim -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 --steps K --warmup W` -- with the real kernels: the ranks are torchrun's processes (bench.py starts
+    none), they bind through LOCAL_RANK, and rank 0 alone prints the compact line with the multi-rank fields and (the N > 1 default) the
+    headline mode + `f16x3` only.  (Two ranks share this box's one GPU over gloo, which they declare with MCNERF_SHARE_GPU=1; with one GPU
+    per rank the same command runs over RCCL and bench.py refuses anything else.)"""
+    import json
+    env = dict(_clean_env(), MCNERF_SHARE_GPU="1", MCNERF_DIST_BACKEND="gloo")
+    full = os.path.join(str(tmp_path), "bench_full.json")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--rays", "2048", "--no-cpu-baseline", "--full-json", full], capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 2048, (len(lines), [len(l) for l in lines])
+    c = json.loads(lines[0])
+    assert c["n_gpus"] == 2 and c["steps"] == 6 and c["warmup"] == 2 and c["scaling"] == "weak"
+    assert c["dist"] == {"world_size": 2, "backend": "gloo", "rccl_ranks": 0, "one_gpu_per_rank": False}
+    assert c["params_identical_across_ranks"] is True and c["asymmetric_grad_steps"] == 0 and c["allreduce_ms"] > 0
+    assert len(c["rank_ms_per_step"]) == 2 and c["f16x3_value"] > 0 and "rho005_value" not in c and "f16_value" not in c
+    # without the declaration a shared GPU is refused: the scaling line is one GPU per rank over RCCL or nothing
+    env2 = dict(_clean_env(), MCNERF_DIST_BACKEND="gloo")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                         "--rays", "2048", "--no-cpu-baseline", "--full-json", full], capture_output=True, text=True, timeout=300, env=env2)
+    assert r2.returncode != 0, r2.stdout[-1500:]          # (rank 1 finds no cuda:1 on a one-GPU box, or rank 0 refuses the gloo backend)
+
+
 @pytest.mark.timeout(420)
 def test_two_ranks_share_one_gpu_data_parallel(gpu_device):
     """N > 1 path with the real HIP backward: two gloo ranks on one GPU (scripts/two_rank_one_gpu.py) - the arena
