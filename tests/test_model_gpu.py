@@ -1466,3 +1466,46 @@ def test_second_backward_through_a_retained_graph_is_refused(gpu_device):
     with pytest.raises(McnerfError, match="ran twice"):
         loss.backward()
     assert sum(len(v) for v in m.ws_pool.free.values()) == n_free          # nothing was pushed a second time
+
+
+def test_a_failing_backward_returns_its_workspaces(gpu_device, monkeypatch):
+    """A backward that raises midway (a kernel refusing its arguments, out of memory) must leave the pool as a completed one does: both
+    nets' saved-operand sets and the gradient workspaces it had taken are back (a retried step then re-uses them instead of allocating
+    another 46 GB), and the retry on the SAME graph is told why it cannot run.  Also the no-gradient way out: only rgb_c is
+    differentiated, so the fine net's set is returned without a backward of its own."""
+    from mc_nerf_amd import ops, synthetic as S
+    from mc_nerf_amd._lib import McnerfError
+    from mc_nerf_amd.model import NeRF_Model
+    dev = gpu_device
+    N = 256
+    sp = S.make_sys_param(dev, samples=32, scale=2, batch=N, H=32, W=32, coarse=(4, 32, [2]), fine=(8, 64, [4]), precision="f16x3h")
+    torch.manual_seed(1)
+    m = NeRF_Model(sp).to(dev)
+    g = torch.Generator().manual_seed(2)
+    o = (torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1) * 3.0).to(dev)
+    d = torch.nn.functional.normalize(-o.cpu() + 0.3 * torch.randn(N, 3, generator=g), dim=-1).to(dev)
+    free = lambda: sum(len(v) for v in m.ws_pool.free.values())
+    # a completed step: what the pool holds afterwards is the yardstick
+    rgb_c, rgb_f = m.render_rays_train(d, o, 0, 1.0)
+    (rgb_c.sum() + rgb_f.sum()).backward()
+    n_done = free()
+    assert n_done >= 4                                               # two save sets + two gradient sets
+    # a backward whose weight-gradient call raises (the FINE net's: the coarse net's set has not reached its own backward yet)
+    rgb_c, rgb_f = m.render_rays_train(d, o, 0, 1.0)
+    assert free() == n_done - 2                                      # the forward holds the two save sets
+    real = ops.mlp_dw
+    def failing(*a, **kw):
+        raise McnerfError("injected failure")
+    monkeypatch.setattr(ops, "mlp_dw", failing)
+    with pytest.raises(McnerfError, match="injected"):
+        (rgb_c.sum() + rgb_f.sum()).backward(retain_graph=True)
+    monkeypatch.setattr(ops, "mlp_dw", real)
+    assert free() == n_done                                          # everything came back
+    with pytest.raises(McnerfError, match="ran twice"):              # ... and the graph cannot be used again
+        (rgb_c.sum() + rgb_f.sum()).backward()
+    assert free() == n_done
+    # only the coarse colour differentiated: the fine net's set goes back without a backward
+    rgb_c, rgb_f = m.render_rays_train(d, o, 0, 1.0)
+    rgb_c.sum().backward()
+    assert free() == n_done
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.nerf_coarse.parameters())
